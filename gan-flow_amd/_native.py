@@ -1,0 +1,220 @@
+"""ctypes binding of libcnf_hip.so (C ABI: include/cnf_hip.h).  PyTorch is plumbing only: it owns the
+device memory and the stream; every number is produced by the HIP kernels.  There is NO fallback: if the
+library is missing or the tensors are not on a HIP device the calls raise."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class CnfError(RuntimeError):
+    """Raised for rejected calls and for integrator failures (wording follows torchdiffeq's assertions)."""
+
+
+class CnfNetDesc(ctypes.Structure):
+    _fields_ = [("dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("n_hidden", ctypes.c_int32),
+                ("divergence", ctypes.c_int32)]
+
+
+class CnfSolverOpts(ctypes.Structure):
+    _fields_ = [("solver", ctypes.c_int32), ("rtol", ctypes.c_float), ("atol", ctypes.c_float),
+                ("step_size", ctypes.c_float), ("tile_rows", ctypes.c_int32), ("max_steps", ctypes.c_int32)]
+
+
+SOLVER_IDS = {"dopri5": 0, "rk4": 1}
+DIV_EXACT, DIV_HUTCHINSON = 0, 1
+STATUS_MESSAGES = {
+    1: "underflow in dt {last_dt}",
+    2: "non-finite values in state `y`",
+    3: "max_num_steps exceeded",
+    4: "grid-wide reduction timed out inside the solver kernel",
+}
+EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
+           "cnf_eval_aug", "cnf_solve_bwd")
+
+
+def library_path():
+    return os.path.join(_HERE, "libcnf_hip.so")
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise CnfError("libcnf_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C gan-flow_amd/csrc`.  There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    P, F, I64, SZ, VP = ctypes.c_void_p, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
+    ND, SO = ctypes.POINTER(CnfNetDesc), ctypes.POINTER(CnfSolverOpts)
+    lib.cnf_param_count.restype = I64
+    lib.cnf_param_count.argtypes = [ND]
+    lib.cnf_workspace_bytes.restype = SZ
+    lib.cnf_workspace_bytes.argtypes = [ND, I64]
+    lib.cnf_last_error.restype = ctypes.c_char_p
+    lib.cnf_last_error.argtypes = []
+    lib.cnf_eval_field.restype = ctypes.c_int
+    lib.cnf_eval_field.argtypes = [ND, P, F, P, P, I64, P, P, VP]
+    lib.cnf_solve_fwd.restype = ctypes.c_int
+    lib.cnf_solve_fwd.argtypes = [ND, P, P, P, P, I64, F, F, SO, P, P, VP, SZ, P, VP]
+    lib.cnf_eval_aug.restype = ctypes.c_int
+    lib.cnf_eval_aug.argtypes = [ND, P, F, P, P, P, P, I64, P, P, P, P, VP, SZ, VP]
+    lib.cnf_solve_bwd.restype = ctypes.c_int
+    lib.cnf_solve_bwd.argtypes = [ND, P, P, P, P, P, P, I64, F, F, SO, P, P, P, VP, SZ, P, VP]
+    _LIB = lib
+    return lib
+
+
+def _check(rc, lib):
+    if rc != 0:
+        raise CnfError(lib.cnf_last_error().decode())
+
+
+def _dev(t, name, shape=None):
+    if t is None:
+        return None
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise CnfError("%s must be a tensor on a HIP device (got %s); the CNF hot path has no CPU fallback"
+                       % (name, getattr(t, "device", type(t))))
+    if t.dtype != torch.float32:
+        raise CnfError("%s must be float32 (got %s)" % (name, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise CnfError("%s must have shape %s (got %s)" % (name, tuple(shape), tuple(t.shape)))
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WORKSPACES = {}
+
+
+def _workspace(lib, net, rows, device):
+    need = int(lib.cnf_workspace_bytes(ctypes.byref(net), rows))
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def net_desc(dim, hidden, n_hidden, hutchinson):
+    return CnfNetDesc(int(dim), int(hidden), int(n_hidden), DIV_HUTCHINSON if hutchinson else DIV_EXACT)
+
+
+def param_count(net):
+    n = load_library().cnf_param_count(ctypes.byref(net))
+    if n < 0:
+        raise CnfError("unsupported net: dim=%d hidden=%d n_hidden=%d divergence=%d"
+                       % (net.dim, net.hidden, net.n_hidden, net.divergence))
+    return int(n)
+
+
+class Stats:
+    """Host view of a CnfStats block (8 int32 words on the device)."""
+
+    def __init__(self, words):
+        w = words.tolist()
+        self.status, self.nfe, self.n_accepted, self.n_rejected = w[0], w[1], w[2], w[3]
+        self.last_dt = torch.tensor([w[4]], dtype=torch.int32).view(torch.float32).item()
+        self.evals_run = w[5]
+        self.row_evals = (w[6] & 0xFFFFFFFF) | ((w[7] & 0xFFFFFFFF) << 32)
+
+    def raise_for_status(self):
+        if self.status:
+            raise CnfError(STATUS_MESSAGES.get(self.status, "solver status %d" % self.status).format(last_dt=self.last_dt))
+
+    def __repr__(self):
+        return ("Stats(status=%d, nfe=%d, accepted=%d, rejected=%d, last_dt=%g, evals_run=%d, row_evals=%d)"
+                % (self.status, self.nfe, self.n_accepted, self.n_rejected, self.last_dt, self.evals_run, self.row_evals))
+
+
+def make_opts(solver="dopri5", rtol=1e-5, atol=1e-5, step_size=None, tile_rows=0, max_steps=0):
+    if solver not in SOLVER_IDS:
+        raise CnfError("solver %r is not built into the HIP path (have: %s)" % (solver, ", ".join(SOLVER_IDS)))
+    return CnfSolverOpts(SOLVER_IDS[solver], float(rtol), float(atol), float(step_size or 0.0), int(tile_rows), int(max_steps))
+
+
+def eval_field(net, params, t, z, e=None):
+    """(f, -div) = ODEfunc.forward(t, (z, .)) for a (rows, dim) batch."""
+    lib = load_library()
+    z = _dev(z, "z")
+    rows = z.shape[0]
+    params = _dev(params, "params", (param_count(net),))
+    e = _dev(e, "e", z.shape) if e is not None else None
+    f = torch.empty_like(z)
+    nd = torch.empty(rows, 1, dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _check(lib.cnf_eval_field(ctypes.byref(net), _ptr(params), float(t), _ptr(z), _ptr(e), rows, _ptr(f), _ptr(nd),
+                                  _stream()), lib)
+    return f, nd
+
+
+def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None):
+    """State (z, logp) at t1 of the CNF ODE started from (x, logp0) at t0.  Returns (z, logp, stats_words)."""
+    lib = load_library()
+    x = _dev(x, "x")
+    rows = x.shape[0]
+    params = _dev(params, "params", (param_count(net),))
+    logp0 = _dev(logp0, "logp0", (rows, 1)) if logp0 is not None else None
+    e = _dev(e, "e", x.shape) if e is not None else None
+    z = torch.empty_like(x)
+    logp = torch.empty(rows, 1, dtype=torch.float32, device=x.device)
+    stats = torch.empty(8, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws = _workspace(lib, net, rows, x.device)
+        _check(lib.cnf_solve_fwd(ctypes.byref(net), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows, float(t0), float(t1),
+                                 ctypes.byref(opts), _ptr(z), _ptr(logp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
+    return z, logp, stats
+
+
+def eval_aug(net, params, t, z, a_z, a_logp, e=None):
+    """One evaluation of the adjoint's augmented dynamics: (f, -div, vjp_z, vjp_params)."""
+    lib = load_library()
+    z = _dev(z, "z")
+    rows = z.shape[0]
+    params = _dev(params, "params", (param_count(net),))
+    a_z = _dev(a_z, "a_z", z.shape)
+    a_logp = _dev(a_logp, "a_logp", (rows, 1))
+    e = _dev(e, "e", z.shape) if e is not None else None
+    f = torch.empty_like(z)
+    nd = torch.empty(rows, 1, dtype=torch.float32, device=z.device)
+    vz = torch.empty_like(z)
+    vp = torch.empty_like(params)
+    with torch.cuda.device(z.device):
+        ws = _workspace(lib, net, rows, z.device)
+        _check(lib.cnf_eval_aug(ctypes.byref(net), _ptr(params), float(t), _ptr(z), _ptr(e), _ptr(a_z), _ptr(a_logp), rows,
+                                _ptr(f), _ptr(nd), _ptr(vz), _ptr(vp), _ptr(ws), ws.numel(), _stream()), lib)
+    return f, nd, vz, vp
+
+
+def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None):
+    """Adjoint pass for the interval [t0, t1]: returns (grad_x, grad_logp0, grad_params, stats_words)."""
+    lib = load_library()
+    z1 = _dev(z1, "z1")
+    rows = z1.shape[0]
+    params = _dev(params, "params", (param_count(net),))
+    logp1 = _dev(logp1, "logp1", (rows, 1))
+    grad_z1 = _dev(grad_z1, "grad_z1", z1.shape)
+    grad_logp1 = _dev(grad_logp1, "grad_logp1", (rows, 1))
+    e = _dev(e, "e", z1.shape) if e is not None else None
+    gx = torch.empty_like(z1)
+    gl = torch.empty_like(logp1)
+    gp = torch.empty_like(params)
+    stats = torch.empty(8, dtype=torch.int32, device=z1.device)
+    with torch.cuda.device(z1.device):
+        ws = _workspace(lib, net, rows, z1.device)
+        _check(lib.cnf_solve_bwd(ctypes.byref(net), _ptr(params), _ptr(z1), _ptr(logp1), _ptr(e), _ptr(grad_z1),
+                                 _ptr(grad_logp1), rows, float(t0), float(t1), ctypes.byref(opts), _ptr(gx), _ptr(gl),
+                                 _ptr(gp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
+    return gx, gl, gp, stats

@@ -1,0 +1,210 @@
+// cnf_api.hip -- the extern "C" surface declared in include/cnf_hip.h: argument checking, workspace
+// carving, launch.  Nothing here allocates or synchronises.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "cnf_launch.h"
+
+namespace cnf {
+hipError_t launch_eval_aug(int D, bool hutch, const SolveArgs& a, float t, const float* z, const float* a_z,
+                           const float* a_logp, float* f_out, float* nd_out, float* vjp_z_out, hipStream_t s);
+hipError_t launch_solve_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
+}  // namespace cnf
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+constexpr size_t kGranBytes = 2 * (size_t)cnf::kMaxWG * 4 * sizeof(unsigned long long);  // 16 KiB
+
+bool supported(const CnfNetDesc* n) {
+    if (!n || n->hidden != cnf::kH || n->n_hidden != 3) return false;
+    const bool hutch = n->divergence == CNF_DIV_HUTCHINSON;
+    if (n->divergence != CNF_DIV_EXACT && !hutch) return false;
+    return (n->dim == 1 && !hutch) || n->dim == 2 || (n->dim == 16 && hutch);
+}
+
+int check_net(const CnfNetDesc* n) {
+    if (!n) return fail("net is NULL");
+    if (!supported(n))
+        return fail("unsupported net: dim=%d hidden=%d n_hidden=%d divergence=%d (built: hidden 64 x 3; dim 1|2 exact, "
+                    "dim 2|16 Hutchinson)", n->dim, n->hidden, n->n_hidden, n->divergence);
+    return 0;
+}
+
+long n_wg(long rows) { return (rows + cnf::kRowsPerWG - 1) / cnf::kRowsPerWG; }
+
+size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+}  // namespace
+
+extern "C" {
+
+const char* cnf_last_error(void) { return g_err.c_str(); }
+
+int64_t cnf_param_count(const CnfNetDesc* net) {
+    if (!supported(net)) return -1;
+    return cnf::make_layout(net->dim, net->hidden).total;
+}
+
+size_t cnf_workspace_bytes(const CnfNetDesc* net, int64_t rows) {
+    if (!supported(net) || rows <= 0) return 0;
+    const size_t P = (size_t)cnf::make_layout(net->dim, net->hidden).total;
+    return kGranBytes + align16((size_t)n_wg(rows) * P * sizeof(float));
+}
+
+int cnf_eval_field(const CnfNetDesc* net, const float* params, float t, const float* z, const float* e,
+                   int64_t rows, float* f_out, float* neg_div_out, void* stream) {
+    if (check_net(net)) return 1;
+    if (!params || !z || !f_out || !neg_div_out) return fail("cnf_eval_field: NULL pointer");
+    if (rows <= 0) return fail("cnf_eval_field: rows must be positive (got %ld)", (long)rows);
+    const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
+    if (hutch && !e) return fail("cnf_eval_field: Hutchinson divergence needs the probe e");
+    hipError_t err = cnf::launch_field(net->dim, hutch, params, t, z, e, rows, f_out, neg_div_out, (hipStream_t)stream);
+    if (err != hipSuccess) return fail("cnf_eval_field: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+static int fill_common(const char* who, const CnfNetDesc* net, const float* params, int64_t rows, float t0, float t1,
+                       const CnfSolverOpts* opts, void* workspace, size_t workspace_bytes, CnfStats* stats,
+                       cnf::SolveArgs& a, bool& global) {
+    if (check_net(net)) return 1;
+    if (!params || !opts || !stats || !workspace) return fail("%s: NULL pointer", who);
+    if (rows <= 0) return fail("%s: rows must be positive (got %ld)", who, (long)rows);
+    if (!(t0 != t1) || !std::isfinite(t0) || !std::isfinite(t1)) return fail("%s: t0 and t1 must be finite and distinct", who);
+    if (((uintptr_t)workspace & 15) != 0) return fail("%s: workspace must be 16-byte aligned", who);
+    const size_t need = cnf_workspace_bytes(net, rows);
+    if (workspace_bytes < need) return fail("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
+    a = cnf::SolveArgs{};
+    a.params = params;
+    a.rows = rows;
+    a.t0 = t0;
+    a.t1 = t1;
+    a.rtol = opts->rtol;
+    a.atol = opts->atol;
+    a.max_steps = opts->max_steps > 0 ? opts->max_steps : (1 << 20);
+    a.gran = (unsigned long long*)workspace;
+    a.slab = (float*)((char*)workspace + kGranBytes);
+    a.stats = stats;
+    a.n_grid = 1;
+    a.step_size = 0.f;
+    global = true;
+    if (opts->solver == CNF_SOLVER_DOPRI5) {
+        if (!(opts->rtol > 0.f) || !(opts->atol > 0.f)) return fail("%s: dopri5 needs rtol > 0 and atol > 0", who);
+        if (opts->tile_rows != 0 && opts->tile_rows != cnf::kRows)
+            return fail("%s: tile_rows must be 0 (batch-global step control) or %d", who, cnf::kRows);
+        global = opts->tile_rows == 0;
+        if (global && n_wg(rows) > cnf::kMaxWG)
+            return fail("%s: batch-global step control supports at most %d rows per solve (got %ld); split the batch into "
+                        "chunks as the reference's evaluation does, or use tile_rows=%d", who,
+                        cnf::kMaxWG * cnf::kRowsPerWG, (long)rows, cnf::kRows);
+    } else if (opts->solver == CNF_SOLVER_RK4) {
+        if (opts->step_size > 0.f) {
+            // the fixed grid of torchdiffeq: ceil((t1-t0)/h + 1) points, the last clipped to t1 (fp32 arithmetic)
+            const float sgn = t1 >= t0 ? 1.f : -1.f;
+            const float tau0 = sgn * t0, tau1 = sgn * t1;
+            const float span = tau1 - tau0;
+            const float q = span / opts->step_size;
+            const float npts = std::ceil(q + 1.0f);
+            if (!(npts >= 2.f) || npts > 1e7f) return fail("%s: rk4 step_size gives an unusable grid (%g points)", who, npts);
+            const float last = (npts - 1.0f) * opts->step_size + tau0;
+            if (last < tau1) return fail("%s: rk4 grid does not reach t1 (torchdiffeq asserts time_grid[-1] == t[-1])", who);
+            a.n_grid = (int)npts - 1;
+            a.step_size = opts->step_size;
+        }
+    } else {
+        return fail("%s: unknown solver %d", who, opts->solver);
+    }
+    return 0;
+}
+
+int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, const float* logp0, const float* e,
+                  int64_t rows, float t0, float t1, const CnfSolverOpts* opts, float* z_out, float* logp_out,
+                  void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream) {
+    cnf::SolveArgs a;
+    bool global;
+    if (fill_common("cnf_solve_fwd", net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
+    if (!x || !z_out || !logp_out) return fail("cnf_solve_fwd: NULL pointer");
+    const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
+    if (hutch && !e) return fail("cnf_solve_fwd: Hutchinson divergence needs the probe e");
+    a.x = x;
+    a.logp0 = logp0;
+    a.e = e;
+    a.z_out = z_out;
+    a.logp_out = logp_out;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = hipMemsetAsync(workspace, 0, kGranBytes, s);
+    if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    if (err == hipSuccess) err = cnf::launch_solve_fwd(net->dim, hutch, a, opts->solver, global, s);
+    if (err != hipSuccess) return fail("cnf_solve_fwd: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const float* z, const float* e, const float* a_z,
+                 const float* a_logp, int64_t rows, float* f_out, float* neg_div_out, float* vjp_z_out,
+                 float* vjp_params_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_net(net)) return 1;
+    if (!params || !z || !a_z || !a_logp || !f_out || !neg_div_out || !vjp_z_out || !vjp_params_out || !workspace)
+        return fail("cnf_eval_aug: NULL pointer");
+    if (rows <= 0) return fail("cnf_eval_aug: rows must be positive (got %ld)", (long)rows);
+    if (n_wg(rows) > cnf::kMaxWG) return fail("cnf_eval_aug: at most %d rows", cnf::kMaxWG * cnf::kRowsPerWG);
+    const size_t need = cnf_workspace_bytes(net, rows);
+    if (workspace_bytes < need) return fail("cnf_eval_aug: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
+    if (hutch && !e) return fail("cnf_eval_aug: Hutchinson divergence needs the probe e");
+    cnf::SolveArgs a{};
+    a.params = params;
+    a.rows = rows;
+    a.e = e;
+    a.gran = (unsigned long long*)workspace;
+    a.slab = (float*)((char*)workspace + kGranBytes);
+    a.grad_params = vjp_params_out;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = hipMemsetAsync(workspace, 0, kGranBytes, s);
+    if (err == hipSuccess) err = cnf::launch_eval_aug(net->dim, hutch, a, t, z, a_z, a_logp, f_out, neg_div_out, vjp_z_out, s);
+    if (err != hipSuccess) return fail("cnf_eval_aug: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, const float* logp1, const float* e,
+                  const float* grad_z1, const float* grad_logp1, int64_t rows, float t0, float t1,
+                  const CnfSolverOpts* opts, float* grad_x, float* grad_logp0, float* grad_params, void* workspace,
+                  size_t workspace_bytes, CnfStats* stats, void* stream) {
+    cnf::SolveArgs a;
+    bool global;
+    if (fill_common("cnf_solve_bwd", net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
+    if (!z1 || !logp1 || !grad_z1 || !grad_logp1 || !grad_x || !grad_logp0 || !grad_params)
+        return fail("cnf_solve_bwd: NULL pointer");
+    if (opts->solver != CNF_SOLVER_DOPRI5) return fail("cnf_solve_bwd: the adjoint pass is built for dopri5 only");
+    if (!global) return fail("cnf_solve_bwd: the adjoint pass needs batch-global step control (tile_rows = 0)");
+    const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
+    if (hutch && !e) return fail("cnf_solve_bwd: Hutchinson divergence needs the probe e");
+    a.x = z1;
+    a.logp0 = logp1;
+    a.e = e;
+    a.grad_z1 = grad_z1;
+    a.grad_logp1 = grad_logp1;
+    a.grad_x = grad_x;
+    a.grad_logp0 = grad_logp0;
+    a.grad_params = grad_params;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = hipMemsetAsync(workspace, 0, kGranBytes, s);
+    if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    if (err == hipSuccess) err = cnf::launch_solve_bwd(net->dim, hutch, a, s);
+    if (err != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+}  // extern "C"

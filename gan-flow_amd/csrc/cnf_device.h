@@ -1,0 +1,367 @@
+// cnf_device.h -- device-side building blocks shared by the forward and adjoint kernels (gfx950 only).
+//
+// Work decomposition (DESIGN.md "Data layout"):
+//   * one wave64 owns 16 batch rows ("a tile") and ALL streams of those rows: the value stream and
+//     the forward-mode tangent streams (d of them for the exact divergence, 1 for Hutchinson);
+//   * a hidden activation vector lives in registers in the C/D layout of v_mfma_f32_16x16x4_f32:
+//     lane = (q, j), q = lane>>4, j = lane&15 = row inside the tile; register (T, r) of the lane holds
+//     feature 16*T + 4*q + r of row j.  That layout is at the same time a valid B operand of the next
+//     layer's MFMA (k index = q), so activations chain from layer to layer with no data movement;
+//   * the weights are the A operand.  They are staged once per workgroup into LDS in operand order
+//     ("images": one ds_read_b128 per lane yields the A operands of four consecutive MFMAs);
+//   * f32-input MFMA is an exact k-ordered fmaf chain (cdna_hip_programming.md section 3), so the
+//     result is an ordinary fp32 matmul -- no reduced precision anywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cnf_hip.h"
+
+namespace cnf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = 16;          // batch rows per wave
+constexpr int kH = 64;             // hidden width handled by these kernels
+constexpr int kNW = 4;             // waves per workgroup
+constexpr int kThreads = kNW * 64;
+constexpr int kRowsPerWG = kNW * kRows;
+constexpr int kMaxWG = 256;        // grid-wide reductions need every workgroup resident: <= 1 per CU
+
+// ---- flat parameter layout (include/cnf_hip.h) -------------------------------------------------
+struct ParamLayout {
+    int w[4], b[4], hb[4], wg[4], bg[4];
+    int total;
+};
+__host__ __device__ inline ParamLayout make_layout(int D, int H) {
+    ParamLayout L{};
+    const int din[4] = {D, H, H, H};
+    const int dout[4] = {H, H, H, D};
+    int off = 0;
+    for (int l = 0; l < 4; ++l) {
+        L.w[l] = off;  off += dout[l] * din[l];
+        L.b[l] = off;  off += dout[l];
+        L.hb[l] = off; off += dout[l];
+        L.wg[l] = off; off += dout[l];
+        L.bg[l] = off; off += dout[l];
+    }
+    L.total = off;
+    return L;
+}
+
+// ---- scalar math -------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float sigmoid_f(float a) {
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-a));
+}
+// tanh accurate to ~1 ulp: odd minimax polynomial below 0.625 (Cephes tanhf), 1 - 2/(e^{2|x|}+1) above.
+__device__ __forceinline__ float tanh_f(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    float p = fmaf(x2, -5.70498872745e-3f, 2.06390887954e-2f);
+    p = fmaf(p, x2, -5.37397155531e-2f);
+    p = fmaf(p, x2, 1.33314422036e-1f);
+    p = fmaf(p, x2, -3.33332819422e-1f);
+    const float small = fmaf(p * x2, x, x);
+    const float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * ax) + 1.0f), x);
+    return ax < 0.625f ? small : big;
+}
+
+// wave-private LDS hand-off between lanes of ONE wave: program order is enough for the hardware
+// (one in-order LDS queue per wave); this only stops the compiler from moving accesses across it.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float xq_sum(float v) {        // sum over the 4 lane quarters (same row j)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ double row16_sum(double v) {   // sum over the 16 rows of a quarter
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+// ---- LDS residents -----------------------------------------------------------------------------
+template <int D>
+struct alignas(16) NetLds {
+    float wimg[2][16][64][4];  // layers 2,3: [layer][Tout*4+Tin][lane][r] = W[16Tout+(lane&15)][16Tin+4(lane>>4)+r]
+    float w1[D][kH];           // layer 1 weight, [input m][feature i]
+    float w4[D][kH];           // layer 4 weight, [output m][feature i]
+    float vec[3][4][kH];       // layers 1..3: bias, hyper_bias, hyper_gate.weight, hyper_gate.bias
+    float vec4[4][16];         // layer 4: the same four vectors (first D entries used)
+};
+
+template <int D>
+struct alignas(16) WaveLds {
+    float gate[3][2][kH];      // per evaluation: g = sigmoid(wg t + bg), c = g*b + hb*t
+    float gate4[2][16];
+    float kst[7][D + 1][kRows];  // Runge-Kutta slopes k1..k7 of (z, logp) for the 16 rows
+};
+
+struct alignas(16) RedLds {
+    double part[kNW][4];
+    double tot[4];
+    int status;
+};
+
+template <int D>
+__device__ inline void stage_net(NetLds<D>& n, const float* __restrict__ p, int tid) {
+    const ParamLayout L = make_layout(D, kH);
+    float* img = &n.wimg[0][0][0][0];
+    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += kThreads) {
+        const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
+        const int row = 16 * (tt >> 2) + (lane & 15);
+        const int col = 16 * (tt & 3) + 4 * (lane >> 4) + r;
+        img[idx] = p[L.w[1 + l] + row * kH + col];
+    }
+    for (int idx = tid; idx < D * kH; idx += kThreads) {
+        const int m = idx / kH, i = idx % kH;
+        n.w1[m][i] = p[L.w[0] + i * D + m];
+        n.w4[m][i] = p[L.w[3] + m * kH + i];
+    }
+    for (int idx = tid; idx < 3 * kH; idx += kThreads) {
+        const int l = idx / kH, i = idx % kH;
+        n.vec[l][0][i] = p[L.b[l] + i];
+        n.vec[l][1][i] = p[L.hb[l] + i];
+        n.vec[l][2][i] = p[L.wg[l] + i];
+        n.vec[l][3][i] = p[L.bg[l] + i];
+    }
+    if (tid < 16) {
+        const bool in = tid < D;
+        n.vec4[0][tid] = in ? p[L.b[3] + tid] : 0.f;
+        n.vec4[1][tid] = in ? p[L.hb[3] + tid] : 0.f;
+        n.vec4[2][tid] = in ? p[L.wg[3] + tid] : 0.f;
+        n.vec4[3][tid] = in ? p[L.bg[3] + tid] : 0.f;
+    }
+}
+
+// gates of all four layers at time t, one feature per lane, into the wave's scratch
+template <int D>
+__device__ __forceinline__ void compute_gates(const NetLds<D>& n, WaveLds<D>& ws, int lane, float t) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const float g = sigmoid_f(fmaf(n.vec[l][2][lane], t, n.vec[l][3][lane]));
+        ws.gate[l][0][lane] = g;
+        ws.gate[l][1][lane] = fmaf(g, n.vec[l][0][lane], n.vec[l][1][lane] * t);
+    }
+    if (lane < 16) {
+        const float g = sigmoid_f(fmaf(n.vec4[2][lane], t, n.vec4[3][lane]));
+        ws.gate4[0][lane] = g;
+        ws.gate4[1][lane] = fmaf(g, n.vec4[0][lane], n.vec4[1][lane] * t);
+    }
+    wave_lds_fence();
+}
+
+// ---- the dynamics: f(t, z) and its divergence for the 16 rows of this wave -----------------------
+// Restates ODEnet.forward + divergence_bf / divergence_approx with
+// forward-mode tangents instead of autograd passes.  z, e: this lane's row (replicated in the 4 quarters).
+// Returns f[D] and div = tr(df/dz) (exact) or e^T (df/dz) e (Hutchinson), identical in all 4 quarters.
+template <int D, bool HUTCH>
+__device__ __forceinline__ void field_fwd(const NetLds<D>& n, WaveLds<D>& ws, int lane, float t,
+                                          const float (&z)[D], const float (&e)[D], float (&f)[D], float& div) {
+    constexpr int NT = HUTCH ? 1 : D;
+    constexpr int NS = NT + 1;
+    const int q = lane >> 4;
+    compute_gates(n, ws, lane, t);
+
+    float act[NS][16];
+    // layer 1: d -> 64 on the vector ALU (K = d is too thin for a matrix op)
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const int fo = 16 * T + 4 * q;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[0][0][fo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[0][1][fo]);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accu = {0.f, 0.f, 0.f, 0.f};
+        f32x4 wcol[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            wcol[m] = *reinterpret_cast<const f32x4*>(&n.w1[m][fo]);
+            acc += wcol[m] * z[m];
+            if (HUTCH) accu += wcol[m] * e[m];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = tanh_f(fmaf(g[r], acc[r], c[r]));
+            const float dg = (1.0f - x * x) * g[r];
+            act[0][4 * T + r] = x;
+            if (HUTCH) {
+                act[1][4 * T + r] = dg * accu[r];
+            } else {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) act[1 + m][4 * T + r] = dg * wcol[m][r];
+            }
+        }
+    }
+    // layers 2, 3: 64 -> 64 on the matrix cores, all streams share the weight operand
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        f32x4 acc[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int To = 0; To < 4; ++To) acc[s][To] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti) {
+            f32x4 a[4];
+#pragma unroll
+            for (int To = 0; To < 4; ++To) a[To] = *reinterpret_cast<const f32x4*>(&n.wimg[l][To * 4 + Ti][lane][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int To = 0; To < 4; ++To)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[s][To] = mfma16(a[To][r], act[s][4 * Ti + r], acc[s][To]);
+        }
+#pragma unroll
+        for (int To = 0; To < 4; ++To) {
+            const int fo = 16 * To + 4 * q;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = tanh_f(fmaf(g[r], acc[0][To][r], c[r]));
+                const float dg = (1.0f - x * x) * g[r];
+                act[0][4 * To + r] = x;
+#pragma unroll
+                for (int s = 1; s < NS; ++s) act[s][4 * To + r] = dg * acc[s][To][r];
+            }
+        }
+    }
+    // layer 4: 64 -> d on the vector ALU; each lane holds 16 of the 64 features of its row
+    float pf[D], pd[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) pf[m] = pd[m] = 0.f;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const int fo = 16 * T + 4 * q;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&n.w4[m][fo]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[m] = fmaf(w[r], act[0][4 * T + r], pf[m]);
+                pd[m] = fmaf(w[r], act[HUTCH ? 1 : 1 + m][4 * T + r], pd[m]);
+            }
+        }
+    }
+    div = 0.f;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        const float g4 = ws.gate4[0][m];
+        f[m] = fmaf(g4, xq_sum(pf[m]), ws.gate4[1][m]);
+        const float dm = g4 * xq_sum(pd[m]);
+        div += HUTCH ? dm * e[m] : dm;
+    }
+}
+
+// ---- Dormand-Prince tableau, rounded to fp32 where the state is fp32 ------
+__device__ const float kAlpha[6] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f, 1.f};
+__device__ const float kBeta[6][6] = {
+    {(float)(1.0 / 5), 0, 0, 0, 0, 0},
+    {(float)(3.0 / 40), (float)(9.0 / 40), 0, 0, 0, 0},
+    {(float)(44.0 / 45), (float)(-56.0 / 15), (float)(32.0 / 9), 0, 0, 0},
+    {(float)(19372.0 / 6561), (float)(-25360.0 / 2187), (float)(64448.0 / 6561), (float)(-212.0 / 729), 0, 0},
+    {(float)(9017.0 / 3168), (float)(-355.0 / 33), (float)(46732.0 / 5247), (float)(49.0 / 176), (float)(-5103.0 / 18656), 0},
+    {(float)(35.0 / 384), 0.f, (float)(500.0 / 1113), (float)(125.0 / 192), (float)(-2187.0 / 6784), (float)(11.0 / 84)},
+};
+__device__ const float kCErr[7] = {
+    (float)(35.0 / 384 - 1951.0 / 21600), 0.f, (float)(500.0 / 1113 - 22642.0 / 50085),
+    (float)(125.0 / 192 - 451.0 / 720), (float)(-2187.0 / 6784 + 12231.0 / 42400),
+    (float)(11.0 / 84 - 649.0 / 6300), (float)(-1.0 / 60)};
+__device__ const float kCMid[7] = {
+    (float)(6025192743.0 / 30085553152.0 / 2), 0.f, (float)(51252292925.0 / 65400821598.0 / 2),
+    (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
+    (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
+
+// step-size update of the controller (Appendix B.5); time bookkeeping is float64 like the original
+__device__ __forceinline__ double next_step_size(double dt, float worst) {
+    if (worst == 0.f) return dt * 10.0;
+    const double inv_dfactor = worst < 1.f ? 1.0 : 5.0;
+    const double root = (double)sqrtf(worst);
+    const double factor = fmax(0.1, fmin(pow(root, 0.2) / 0.9, inv_dfactor));
+    return dt / factor;
+}
+
+// python's max(a, b) over a 2-tuple: keeps `a` unless b > a (so a NaN in `a` sticks, one in `b` is ignored)
+__device__ __forceinline__ float pymax(float a, float b) { return b > a ? b : a; }
+
+// ---- grid-wide reduction of up to 4 doubles -----------------------------------------------------
+// Every workgroup publishes its partial as four 8-byte {epoch, value} granules (one sc1 store each: the
+// data is its own flag, cdna_hip_programming.md Guideline 16 form R2) and wave 0 of every workgroup
+// sweeps all granules until every tag equals the epoch, then adds them in a fixed order: all
+// workgroups obtain bit-identical totals, so they take identical accept/reject decisions.  Two
+// granule banks alternate by epoch parity (a workgroup can be at most one reduction ahead).
+struct GridSync {
+    unsigned long long* gran;  // [2][nwg*4]
+    int nwg;
+    unsigned epoch;
+};
+
+constexpr unsigned kSpinLimit = 1u << 24;
+
+// returns false on timeout (status set in red.status).  All threads of the workgroup must call it.
+__device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = row16_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red.part[w][i] = v[i];
+    }
+    __syncthreads();
+    if (w == 0) {
+        double s = 0.0;
+        if (lane < 4) s = red.part[0][lane] + red.part[1][lane] + red.part[2][lane] + red.part[3][lane];
+        if (gs.nwg > 1) {
+            gs.epoch += 1;
+            unsigned long long* bank = gs.gran + (size_t)(gs.epoch & 1u) * (size_t)(gs.nwg * 4);
+            if (lane < 4) {
+                const unsigned long long pk = ((unsigned long long)gs.epoch << 32) | (unsigned long long)__float_as_uint((float)s);
+                __hip_atomic_store(bank + blockIdx.x * 4 + lane, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int ng = gs.nwg * 4;
+            double acc = 0.0;
+            bool done = false;
+            for (unsigned spin = 0; spin < kSpinLimit; ++spin) {
+                bool ok = true;
+                acc = 0.0;
+                for (int g = lane; g < ng; g += 64) {
+                    const unsigned long long x = __hip_atomic_load(bank + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok &= (unsigned)(x >> 32) == gs.epoch;
+                    acc += (double)__uint_as_float((unsigned)x);
+                }
+                if (__all(ok)) { done = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!done && lane == 0) red.status = CNF_ERR_SYNC_TIMEOUT;
+            acc += __shfl_xor(acc, 4);
+            acc += __shfl_xor(acc, 8);
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            s = acc;
+        }
+        if (lane < 4) red.tot[lane] = s;
+    } else {
+        gs.epoch += (gs.nwg > 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = red.tot[i];
+    return red.status == 0;
+}
+
+// tile-local variant: the 16 rows of this wave are the whole control group
+__device__ __forceinline__ void wave_allreduce4(double (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = row16_sum(v[i]);
+}
+
+}  // namespace cnf

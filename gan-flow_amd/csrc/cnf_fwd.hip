@@ -1,0 +1,379 @@
+// cnf_fwd.hip -- forward kernels: one field evaluation, fixed-grid RK4, adaptive dopri5 (gfx950).
+//
+// These replace, inside CNF.forward, torchdiffeq's `odeint(func, (z, logp), [t0, t1], method=...)`
+// (controller restated from Appendix B).  One persistent launch
+// integrates the whole interval: weights are staged in LDS once, each wave keeps the state of its
+// 16 rows in registers, the Runge-Kutta slopes in wave-private LDS.
+#include "cnf_launch.h"
+
+namespace cnf {
+
+// ------------------------------------------------------------------------------------------------
+// single evaluation (ODEfunc.forward)
+// ------------------------------------------------------------------------------------------------
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict__ params, float t,
+                                                         const float* __restrict__ z, const float* __restrict__ e,
+                                                         long rows, float* __restrict__ f_out,
+                                                         float* __restrict__ neg_div_out) {
+    __shared__ NetLds<D> net;
+    __shared__ WaveLds<D> wl[kNW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    stage_net(net, params, tid);
+    __syncthreads();
+    const long base = ((long)blockIdx.x * kNW + w) * kRows;
+    if (base >= rows) return;
+    const long row = base + j;
+    const long rr = row < rows ? row : rows - 1;
+    float zz[D], ee[D], f[D], div;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        zz[m] = z[rr * D + m];
+        ee[m] = HUTCH ? e[rr * D + m] : 0.f;
+    }
+    field_fwd<D, HUTCH>(net, wl[w], lane, t, zz, ee, f, div);
+    if (lane < 16 && row < rows) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) f_out[row * D + m] = f[m];
+        neg_div_out[row] = -div;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed-grid RK4, 3/8 rule (Appendix B.6).  No cross-row coupling: waves are independent.
+// ------------------------------------------------------------------------------------------------
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void rk4_kernel(SolveArgs a) {
+    __shared__ NetLds<D> net;
+    __shared__ WaveLds<D> wl[kNW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    stage_net(net, a.params, tid);
+    __syncthreads();
+    const long base = ((long)blockIdx.x * kNW + w) * kRows;
+    if (base >= a.rows) return;
+    const long row = base + j;
+    const long rr = row < a.rows ? row : a.rows - 1;
+    constexpr int C = D + 1;
+    float y[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+    }
+    y[D] = a.logp0 ? a.logp0[rr] : 0.f;
+    const float sgn = a.t1 >= a.t0 ? 1.f : -1.f;
+    const float tau0 = sgn * a.t0, tau1 = sgn * a.t1;
+
+    for (int step = 0; step < a.n_grid; ++step) {
+        // grid point i = i*step_size + tau0 (product rounded before the add, like arange()*h + t0)
+        float ta = a.n_grid == 1 ? tau0 : __fadd_rn(__fmul_rn((float)step, a.step_size), tau0);
+        float tb = (step + 1 == a.n_grid) ? tau1 : __fadd_rn(__fmul_rn((float)(step + 1), a.step_size), tau0);
+        const float dt = tb - ta;
+        float k1[C], k2[C], k3[C], yi[C];
+        float ti = ta;
+#pragma unroll
+        for (int c = 0; c < C; ++c) yi[c] = y[c];
+        for (int st = 0; st < 4; ++st) {
+            float zz[D], f[D], div, k[C];
+#pragma unroll
+            for (int m = 0; m < D; ++m) zz[m] = yi[m];
+            field_fwd<D, HUTCH>(net, wl[w], lane, sgn * ti, zz, ee, f, div);
+#pragma unroll
+            for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
+            k[D] = -sgn * div;
+            if (st == 0) {
+                ti = ta + dt / 3;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k1[c] = k[c]; yi[c] = y[c] + dt * k[c] / 3; }
+            } else if (st == 1) {
+                ti = ta + dt * 2 / 3;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k2[c] = k[c]; yi[c] = y[c] + dt * (k1[c] / -3 + k[c]); }
+            } else if (st == 2) {
+                ti = ta + dt;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k3[c] = k[c]; yi[c] = y[c] + dt * (k1[c] - k2[c] + k[c]); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + (k1[c] + 3 * k2[c] + 3 * k3[c] + k[c]) * (dt / 8);
+            }
+        }
+    }
+    if (lane < 16 && row < a.rows) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) a.z_out[row * D + m] = y[m];
+        a.logp_out[row] = y[D];
+    }
+    if (lane == 0) {
+        atomicMax(&a.stats->nfe, 4 * a.n_grid);
+        atomicMax(&a.stats->n_accepted, a.n_grid);
+        atomicMax(&a.stats->evals_run, 4 * a.n_grid);
+        long nrow = a.rows - base < kRows ? a.rows - base : kRows;
+        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(nrow * 4 * a.n_grid));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive Dormand-Prince 5(4) with FSAL and quartic dense output (Appendix B.2-B.6)
+//   GLOBAL = true : one (t, dt) for the whole batch; error ratio = mean over the whole batch per
+//                   state tensor (reference semantics) -> one grid-wide reduction per attempt
+//   GLOBAL = false: every 16-row tile (one wave) runs its own controller; waves never synchronise
+// The loop is a small state machine around ONE inlined copy of the dynamics.
+// ------------------------------------------------------------------------------------------------
+template <int D, bool HUTCH, bool GLOBAL>
+__global__ __launch_bounds__(kThreads) void dopri5_kernel(SolveArgs a) {
+    __shared__ NetLds<D> net;
+    __shared__ WaveLds<D> wl[kNW];
+    __shared__ RedLds red;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    constexpr int C = D + 1;
+    if (tid == 0) red.status = 0;
+    stage_net(net, a.params, tid);
+    __syncthreads();
+    const long base = ((long)blockIdx.x * kNW + w) * kRows;
+    if (!GLOBAL && base >= a.rows) return;
+    const long row = base + j;
+    const bool counted = row < a.rows && lane < 16;  // this lane's row enters the norms exactly once
+    const long rr = row < a.rows ? row : a.rows - 1;
+    WaveLds<D>& ws = wl[w];
+
+    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    double nz, nl;  // element counts of the z and logp tensors of the control group
+    if (GLOBAL) {
+        nl = (double)a.rows;
+    } else {
+        nl = (double)(a.rows - base < kRows ? a.rows - base : kRows);
+    }
+    nz = nl * D;
+
+    float y0[C], y1[C], yi[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y0[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+    }
+    y0[D] = a.logp0 ? a.logp0[rr] : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) yi[c] = y0[c];
+
+    const float sgn = a.t1 >= a.t0 ? 1.f : -1.f;
+    const double tau_end = (double)(sgn * a.t1);
+    double tau = (double)(sgn * a.t0);  // start of the current step
+    double dt = 0.0;
+    float dtf = 0.f, t0f = (float)tau, ti = t0f;
+    const float rtol = a.rtol, atol = a.atol;
+
+    enum { PH_F0 = 0, PH_F1 = 1, PH_STAGE = 2 };
+    int phase = PH_F0, stage = 0;
+    int nfe = 0, nacc = 0, nrej = 0, status = 0;
+    float h0 = 0.f, d1z = 0.f, d1l = 0.f;
+    float sc[C];  // initial-step scale, atol + |y0| * rtol
+
+    for (;;) {
+        float zz[D], f[D], div, k[C];
+        bool restart = false;
+#pragma unroll
+        for (int m = 0; m < D; ++m) zz[m] = yi[m];
+        field_fwd<D, HUTCH>(net, ws, lane, sgn * ti, zz, ee, f, div);
+        ++nfe;
+#pragma unroll
+        for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
+        k[D] = -sgn * div;
+
+        if (phase == PH_F0) {
+            // ---- f0 and the first half of the initial-step heuristic (B.2)
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                ws.kst[0][c][j] = k[c];
+                sc[c] = atol + fabsf(y0[c]) * rtol;
+                const float u = y0[c] / sc[c], v = k[c] / sc[c];
+                if (counted) {
+                    S[c < D ? 0 : 1] += (double)u * u;
+                    S[c < D ? 2 : 3] += (double)v * v;
+                }
+            }
+            if (GLOBAL) {
+                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            } else {
+                wave_allreduce4(S);
+            }
+            const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
+            d1z = (float)sqrt(S[2] / nz);
+            d1l = (float)sqrt(S[3] / nl);
+            if (pymax(d0z, d0l) < 1e-5f || pymax(d1z, d1l) < 1e-5f) {
+                h0 = 1e-6f;
+            } else {
+                h0 = 0.01f * pymax(d0z / d1z, d0l / d1l);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) yi[c] = y0[c] + h0 * k[c];
+            ti = t0f + h0;
+            phase = PH_F1;
+            continue;
+        }
+        if (phase == PH_F1) {
+            // ---- second half: curvature estimate, first step size
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float u = (k[c] - ws.kst[0][c][j]) / sc[c];
+                if (counted) S[c < D ? 0 : 1] += (double)u * u;
+            }
+            if (GLOBAL) {
+                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            } else {
+                wave_allreduce4(S);
+            }
+            const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
+            float h1;
+            if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
+                h1 = fmaxf(1e-6f, h0 * 1e-3f);
+            } else {
+                h1 = powf(0.01f / pymax(pymax(pymax(d1z, d1l), d2z), d2l), 0.2f);
+            }
+            dt = (double)fminf(100.f * h0, h1);
+            restart = true;
+        } else {
+            // ---- a Runge-Kutta stage finished: k is slope number stage+1
+#pragma unroll
+            for (int c = 0; c < C; ++c) ws.kst[stage][c][j] = k[c];
+            if (stage < 6) {
+                ++stage;
+            } else {
+                // all seven slopes known: yi is the candidate y1, k its slope (FSAL)
+                double S[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    y1[c] = yi[c];
+                    float err = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c]));
+                    const float u = err / tol;
+                    if (counted) {
+                        S[c < D ? 0 : 1] += (double)u * u;
+                        if (!isfinite(y0[c])) S[2] += 1.0;
+                    }
+                }
+                if (GLOBAL) {
+                    if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                } else {
+                    wave_allreduce4(S);
+                }
+                if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
+                const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
+                const bool accept = (rz <= 1.f) && (rl <= 1.f);
+                if (accept) {
+                    ++nacc;
+                    if (!(tau_end > tau + dt)) break;  // the step reaches the end time: interpolate below
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        y0[c] = y1[c];
+                        ws.kst[0][c][j] = k[c];
+                    }
+                    tau = tau + dt;
+                } else {
+                    ++nrej;
+                }
+                dt = next_step_size(dt, pymax(rz, rl));
+                restart = true;
+            }
+        }
+        // (re)start a step from (tau, y0): after the initial-step heuristic and after every finished attempt
+        if (restart) {
+            if (!(tau + dt > tau)) { status = CNF_ERR_DT_UNDERFLOW; break; }
+            if (nacc + nrej >= a.max_steps) { status = CNF_ERR_MAX_STEPS; break; }
+            dtf = (float)dt;
+            t0f = (float)tau;
+            stage = 1;
+            phase = PH_STAGE;
+        }
+        // input of stage `stage` (computes slope number stage+1): y0 + sum_j (dt*beta[stage-1][j]) k_j
+        ti = t0f + kAlpha[stage - 1] * dtf;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+            for (int s = 0; s < stage; ++s) acc += (dtf * kBeta[stage - 1][s]) * ws.kst[s][c][j];
+            yi[c] = y0[c] + acc;
+        }
+    }
+
+    if (status == 0) {
+        // quartic dense output at tau_end inside the accepted step [tau, tau+dt] (B.6)
+        const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+        const float x = (te - ta) / (tb - ta);
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float mid = 0.f;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * ws.kst[s][c][j];
+            mid = y0[c] + mid;
+            const float f0 = ws.kst[0][c][j], f1 = ws.kst[6][c][j], u = y0[c], v = y1[c];
+            const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
+            const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
+            const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
+            const float cd = dtf * f0;
+            y1[c] = ca * x4 + cb * x3 + cc * x2 + cd * x + u;
+        }
+        if (counted) {
+#pragma unroll
+            for (int m = 0; m < D; ++m) a.z_out[row * D + m] = y1[m];
+            a.logp_out[row] = y1[D];
+        }
+    }
+    if (lane == 0 && (!GLOBAL || (blockIdx.x == 0 && w == 0) || status != 0)) {
+        if (status) atomicMax(&a.stats->status, status);
+        atomicMax(&a.stats->nfe, nfe);
+        atomicMax(&a.stats->n_accepted, nacc);
+        atomicMax(&a.stats->n_rejected, nrej);
+        atomicMax(&a.stats->evals_run, nfe);
+        a.stats->last_dt = (float)dt;
+        const long nrow = GLOBAL ? a.rows : (a.rows - base < kRows ? a.rows - base : kRows);
+        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(nrow * nfe));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <int D, bool HUTCH>
+static hipError_t launch_field_t(const float* params, float t, const float* z, const float* e, long rows,
+                                 float* f_out, float* nd_out, hipStream_t s) {
+    const int grid = (int)((rows + kRowsPerWG - 1) / kRowsPerWG);
+    hipLaunchKernelGGL((field_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, params, t, z, e, rows, f_out, nd_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
+                        float* f_out, float* nd_out, hipStream_t s) {
+    if (D == 1 && !hutch) return launch_field_t<1, false>(params, t, z, e, rows, f_out, nd_out, s);
+    if (D == 2 && !hutch) return launch_field_t<2, false>(params, t, z, e, rows, f_out, nd_out, s);
+    if (D == 2 && hutch) return launch_field_t<2, true>(params, t, z, e, rows, f_out, nd_out, s);
+    if (D == 16 && hutch) return launch_field_t<16, true>(params, t, z, e, rows, f_out, nd_out, s);
+    return hipErrorInvalidValue;
+}
+
+template <int D, bool HUTCH>
+static hipError_t launch_solve_t(const SolveArgs& a, int solver, bool global, hipStream_t s) {
+    const int grid = (int)((a.rows + kRowsPerWG - 1) / kRowsPerWG);
+    if (solver == CNF_SOLVER_RK4) {
+        hipLaunchKernelGGL((rk4_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    } else if (global) {
+        hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, true>), dim3(grid), dim3(kThreads), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_solve_fwd(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s) {
+    if (D == 1 && !hutch) return launch_solve_t<1, false>(a, solver, global, s);
+    if (D == 2 && !hutch) return launch_solve_t<2, false>(a, solver, global, s);
+    if (D == 2 && hutch) return launch_solve_t<2, true>(a, solver, global, s);
+    if (D == 16 && hutch) return launch_solve_t<16, true>(a, solver, global, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cnf

@@ -1,0 +1,35 @@
+// cnf_launch.h -- kernel argument block and launcher prototypes shared by the .hip translation units.
+#pragma once
+#include "cnf_device.h"
+
+namespace cnf {
+
+struct SolveArgs {
+    const float* params;
+    const float* x;       // state at t0 (rows x D)
+    const float* logp0;   // nullable
+    const float* e;       // Hutchinson probe (rows x D) or null
+    float* z_out;
+    float* logp_out;
+    long rows;
+    float t0, t1;
+    float rtol, atol;
+    float step_size;      // rk4 grid spacing (only read when n_grid > 1)
+    int n_grid;           // rk4 number of steps
+    int max_steps;
+    unsigned long long* gran;  // grid-reduction granules, zeroed before the launch
+    CnfStats* stats;           // zeroed before the launch
+    // adjoint only
+    const float* grad_z1;
+    const float* grad_logp1;
+    float* grad_x;
+    float* grad_logp0;
+    float* grad_params;
+    float* slab;          // per-workgroup parameter-gradient partials [nwg][P]
+};
+
+hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
+                        float* f_out, float* nd_out, hipStream_t s);
+hipError_t launch_solve_fwd(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
+
+}  // namespace cnf

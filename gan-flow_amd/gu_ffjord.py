@@ -1,0 +1,138 @@
+"""FFJORD on the Gaussian-uniform mixtures: model builder, eval transforms, loss and the training driver.
+
+Stands in for the reference's `ffjord.gu_ffjord` / `ffjord.gu_maf` (imported at /root/reference/model_plot.py:2, run as
+`python3 -m ffjord.gu_maf --gu_num {1,8}` per /root/reference/README.md:41,57; defaults 50 000 iterations, batch 2 048,
+README.md:28).  Run:  python -m gan_flow_amd.gu_maf --gu_num 8 --niters 50000 --batch_size 2048
+"""
+import argparse
+import math
+import os
+import time
+
+import torch
+
+from .gu import make_gu
+from .lib.layers import CNF, ODEfunc, ODEnet, SequentialFlow
+from .util import count_parameters, get_logger, makedirs, w_distance
+
+
+def build_model(dim=2, dims=(64, 64, 64), num_blocks=1, time_length=0.5, train_T=True, divergence_fn="brute_force",
+                solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False):
+    """`num_blocks` CNF blocks over a dim -> dims -> dim concatsquash/tanh ODEnet: the architecture stored in the
+    reference's checkpoints."""
+    blocks = []
+    for _ in range(num_blocks):
+        net = ODEnet(tuple(dims), (dim,), strides=None, conv=False, layer_type="concatsquash", nonlinearity="tanh")
+        fn = ODEfunc(net, divergence_fn=divergence_fn, residual=False, rademacher=rademacher)
+        blocks.append(CNF(fn, T=time_length, train_T=train_T, regularization_fns=(), solver=solver, atol=atol, rtol=rtol))
+    return SequentialFlow(blocks)
+
+
+def get_transforms(model):
+    """-> (sample_fn, density_fn) as used at /root/reference/model_plot.py:94-98."""
+
+    def sample_fn(z, logpz=None):
+        return model(z, reverse=True) if logpz is None else model(z, logpz, reverse=True)
+
+    def density_fn(x, logpx=None):
+        return model(x, reverse=False) if logpx is None else model(x, logpx, reverse=False)
+
+    return sample_fn, density_fn
+
+
+def standard_normal_logprob(z):
+    return -0.5 * math.log(2 * math.pi) - z.pow(2) / 2
+
+
+def compute_loss(model, x):
+    """Negative mean log-likelihood of a batch under the flow."""
+    zero = torch.zeros(x.shape[0], 1).to(x)
+    z, delta_logp = model(x, zero)
+    logpz = standard_normal_logprob(z).view(z.shape[0], -1).sum(1, keepdim=True)
+    return -torch.mean(logpz - delta_logp)
+
+
+def count_nfe(model):
+    return sum(block.num_evals() for block in model.chain)
+
+
+def evaluate_w_distance(model, data, eval_size=100000, chunk=10000, device=None):
+    """The reference's sampling protocol (model_plot.py:93-101): eval_size prior draws pushed through sample_fn in
+    10 000-row chunks, 1-D Wasserstein distance of the first coordinate against fresh data."""
+    device = device or next(model.parameters()).device
+    dim = model.chain[0].odefunc.odefunc.diffeq.dims[0]
+    was_training = model.training
+    model.eval()
+    sample_fn, _ = get_transforms(model)
+    with torch.no_grad():
+        z = torch.randn(eval_size, dim, device=device)
+        fake = torch.cat([sample_fn(zc) for zc in torch.split(z, chunk)], 0)
+        real = data.get_sample(eval_size).to(device)
+    model.train(was_training)
+    return w_distance(real[:, 0], fake[:, 0])
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser("FFJORD CNF on the Gaussian-uniform mixture (MI355X HIP path)")
+    p.add_argument("--gu_num", type=int, default=8, help="1 = unimodal, 8 = multimodal")
+    p.add_argument("--cuda", type=int, default=0, help="device index")
+    p.add_argument("--niters", type=int, default=50000)
+    p.add_argument("--batch_size", type=int, default=2048)
+    p.add_argument("--log_interval", type=int, default=1000)
+    p.add_argument("--lr", type=float, default=1e-3)
+    p.add_argument("--weight_decay", type=float, default=1e-5)
+    p.add_argument("--dims", type=str, default="64-64-64")
+    p.add_argument("--num_blocks", type=int, default=1)
+    p.add_argument("--time_length", type=float, default=0.5)
+    p.add_argument("--train_T", type=eval, default=True, choices=[True, False])
+    p.add_argument("--divergence_fn", type=str, default="brute_force", choices=["brute_force", "approximate"])
+    p.add_argument("--solver", type=str, default="dopri5", choices=["dopri5", "rk4"])
+    p.add_argument("--atol", type=float, default=1e-5)
+    p.add_argument("--rtol", type=float, default=1e-5)
+    p.add_argument("--step_size", type=float, default=None)
+    p.add_argument("--eval_size", type=int, default=100000)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--save", type=str, default="experiments/gu_ffjord")
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("gu_ffjord needs a HIP device: the CNF integrator is a gfx950 kernel and has no CPU fallback")
+    device = torch.device("cuda:%d" % args.cuda)
+    torch.cuda.set_device(device)
+    makedirs(args.save)
+    logger = get_logger(os.path.join(args.save, "logs"))
+    logger.info(str(args))
+    data = make_gu(args.gu_num, device="cpu", seed=args.seed, extend_dim=True)
+    torch.manual_seed(args.seed)
+    model = build_model(2, tuple(int(d) for d in args.dims.split("-")), args.num_blocks, args.time_length, args.train_T,
+                        args.divergence_fn, args.solver, args.atol, args.rtol).to(device)
+    if args.step_size:
+        for block in model.chain:
+            block.solver_options["step_size"] = args.step_size
+    logger.info("parameters: %d" % count_parameters(model))
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    model.train()
+    t_last = time.time()
+    for itr in range(1, args.niters + 1):
+        optimizer.zero_grad(set_to_none=True)
+        x = data.get_sample(args.batch_size).to(device)
+        loss = compute_loss(model, x)
+        nfe_f = count_nfe(model)
+        loss.backward()
+        nfe_t = count_nfe(model)
+        optimizer.step()
+        if itr % args.log_interval == 0 or itr == 1:
+            now = time.time()
+            wd = evaluate_w_distance(model, data, args.eval_size, device=device)
+            logger.info("iter %06d | loss %.6f | NFE fwd %d bwd %d | %.3f s/iter (incl. logging) | W-distance %.4f"
+                        % (itr, loss.item(), nfe_f, nfe_t - nfe_f, (now - t_last) / max(1, args.log_interval if itr > 1 else 1), wd))
+            torch.save(model.state_dict(), os.path.join(args.save, "ffjord_state_dict.pth"))
+            t_last = time.time()
+    return model
+
+
+if __name__ == "__main__":
+    main()

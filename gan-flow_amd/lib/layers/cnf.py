@@ -1,0 +1,116 @@
+"""CNF block with the reference's signature and attributes (ffjord/lib/layers/cnf.py; SURVEY.md section 2a, section 8a
+row a7, section 8b).  Where the reference calls `odeint_adjoint(self.odefunc, (z, logpz), integration_times, atol=[a, a],
+rtol=[r, r], method=self.solver, options=self.solver_options)`, this class makes ONE typed call into libcnf_hip.so
+for the forward solve and one for the adjoint pass (torch.autograd.Function below).  Tensors must live on a HIP
+device: there is no CPU path."""
+import torch
+import torch.nn as nn
+
+from ... import _native
+from .wrappers.cnf_regularization import RegularizedODEfunc
+
+
+def _inner(odefunc):
+    return odefunc.odefunc if isinstance(odefunc, RegularizedODEfunc) else odefunc
+
+
+class _Solve(torch.autograd.Function):
+    """(z0, logp0, theta) -> (z1, logp1); backward = the adjoint ODE, integrated by the HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, z, logp, flat_params, block, t0, t1, opts, net, e):
+        z1, logp1, stats = _native.solve_fwd(net, flat_params.detach(), z.detach(), logp.detach(), t0, t1, opts, e)
+        block._after_solve(stats, backward=False)
+        ctx.block, ctx.t0, ctx.t1, ctx.opts, ctx.net = block, t0, t1, opts, net
+        ctx.save_for_backward(z1, logp1, flat_params.detach(), e if e is not None else z.new_zeros(0))
+        return z1, logp1
+
+    @staticmethod
+    def backward(ctx, grad_z, grad_logp):
+        z1, logp1, flat_params, e = ctx.saved_tensors
+        e = e if e.numel() else None
+        grad_z = torch.zeros_like(z1) if grad_z is None else grad_z
+        grad_logp = torch.zeros_like(logp1) if grad_logp is None else grad_logp
+        gx, gl, gp, stats = _native.solve_bwd(ctx.net, flat_params, z1, logp1, grad_z, grad_logp, ctx.t0, ctx.t1,
+                                              ctx.opts, e)
+        ctx.block._after_solve(stats, backward=True)
+        return gx, gl, gp, None, None, None, None, None, None
+
+
+class CNF(nn.Module):
+    def __init__(self, odefunc, T=1.0, train_T=False, regularization_fns=None, solver="dopri5", atol=1e-5, rtol=1e-5):
+        super().__init__()
+        root = torch.sqrt(torch.tensor(float(T)))
+        if train_T:
+            self.register_parameter("sqrt_end_time", nn.Parameter(root))
+        else:
+            self.register_buffer("sqrt_end_time", root)
+        nreg = 0
+        if regularization_fns is not None:
+            odefunc = RegularizedODEfunc(odefunc, regularization_fns)
+            nreg = len(regularization_fns)
+        self.odefunc = odefunc
+        self.nreg = nreg
+        self.regularization_states = None
+        self.solver = solver
+        self.atol = atol
+        self.rtol = rtol
+        self.test_solver = solver
+        self.test_atol = atol
+        self.test_rtol = rtol
+        self.solver_options = {}
+        # not in the reference: knobs of the fused integrator
+        self.tile_rows = 0          # 0 = one step size for the whole batch (reference semantics); 16 = per-tile control
+        self.sync_stats = True      # read the solver status back after every solve (one host sync, as the reference has)
+        self.last_stats = {}
+
+    # ------------------------------------------------------------------------------------------------
+    def _after_solve(self, stats_words, backward):
+        inner = _inner(self.odefunc)
+        if backward:
+            # the reference's counter keeps running through backward(): +1 for f(T, y_T), then the augmented stages
+            inner._num_evals += (stats_words[1] + 1).to(inner._num_evals)
+        else:
+            inner._num_evals.copy_(stats_words[1])
+        key = "backward" if backward else "forward"
+        if self.sync_stats:
+            st = _native.Stats(stats_words)
+            self.last_stats[key] = st
+            st.raise_for_status()
+        else:
+            self.last_stats[key] = stats_words
+
+    def forward(self, z, logpz=None, integration_times=None, reverse=False):
+        if not z.is_cuda:
+            raise _native.CnfError("CNF.forward needs tensors on a HIP device (got %s): the integrator is a HIP kernel "
+                                   "and has no CPU fallback" % z.device)
+        _logpz = torch.zeros(z.shape[0], 1).to(z) if logpz is None else logpz
+        if integration_times is None:
+            t0, t1 = 0.0, float(self.sqrt_end_time.detach() * self.sqrt_end_time.detach())
+        else:
+            if len(integration_times) != 2:
+                raise NotImplementedError("the fused integrator returns the state at the end time only")
+            t0, t1 = float(integration_times[0]), float(integration_times[1])
+        if reverse:
+            t0, t1 = t1, t0
+        self.odefunc.before_odeint()
+        inner = _inner(self.odefunc)
+        if self.training:
+            solver, atol, rtol, options = self.solver, self.atol, self.rtol, self.solver_options
+        else:
+            solver, atol, rtol, options = self.test_solver, self.test_atol, self.test_rtol, {}
+        opts = _native.make_opts(solver, rtol, atol, options.get("step_size"), self.tile_rows, options.get("max_num_steps", 0))
+        net = inner.net_desc()
+        e = inner.probe(z)
+        flat = inner.diffeq.flat_parameters()
+        z_t, logpz_t = _Solve.apply(z, _logpz, flat, self, t0, t1, opts, net, e)
+        self.regularization_states = ()
+        return (z_t, logpz_t) if logpz is not None else z_t
+
+    def get_regularization_states(self):
+        reg_states = self.regularization_states
+        self.regularization_states = None
+        return reg_states
+
+    def num_evals(self):
+        return self.odefunc._num_evals.item()

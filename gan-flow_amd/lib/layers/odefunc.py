@@ -1,0 +1,108 @@
+"""ODEnet / ODEfunc with the reference's constructor signatures and attribute names
+(ffjord/lib/layers/odefunc.py).  The arithmetic of the dynamics and of its
+divergence lives in gan-flow_amd/csrc (forward-mode tangents on the matrix cores); these classes hold the
+parameters, the evaluation counter and the Hutchinson probe, and describe the net to the kernels."""
+import torch
+import torch.nn as nn
+
+from ... import _native
+from .diffeq_layers.basic import ConcatSquashLinear
+
+
+def divergence_bf(dx, y, **unused_kwargs):
+    """Marker for the exact-trace divergence (`--divergence_fn brute_force`).  The HIP path computes it with d
+    forward-mode tangent streams; it is never evaluated through autograd."""
+    raise NotImplementedError("divergence_bf is evaluated inside the fused HIP kernels, not as a Python function")
+
+
+def divergence_approx(f, y, e=None):
+    """Marker for the Hutchinson estimator (`--divergence_fn approximate`), see divergence_bf."""
+    raise NotImplementedError("divergence_approx is evaluated inside the fused HIP kernels, not as a Python function")
+
+
+class ODEnet(nn.Module):
+    """dim -> hidden_dims -> dim stack of ConcatSquashLinear layers with tanh between (not after) them."""
+
+    def __init__(self, hidden_dims, input_shape, strides=None, conv=False, layer_type="concatsquash",
+                 nonlinearity="tanh", num_squeeze=0):
+        super().__init__()
+        if conv or layer_type != "concatsquash" or nonlinearity != "tanh" or num_squeeze != 0:
+            raise NotImplementedError("the HIP path is built for the reference's configuration: "
+                                      "layer_type='concatsquash', nonlinearity='tanh', no conv/squeeze")
+        self.num_squeeze = num_squeeze
+        dims = (int(input_shape[0]),) + tuple(int(h) for h in hidden_dims) + (int(input_shape[0]),)
+        self.layers = nn.ModuleList(ConcatSquashLinear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.activation_fns = nn.ModuleList(nn.Tanh() for _ in range(len(dims) - 2))
+
+    @property
+    def dims(self):
+        return (self.layers[0]._layer.in_features,) + tuple(l._layer.out_features for l in self.layers)
+
+    def flat_parameters(self):
+        """The parameter vector in the order include/cnf_hip.h documents (== self.parameters() order)."""
+        return torch.cat([p.reshape(-1) for p in self.parameters()])
+
+    def forward(self, t, y):
+        h = y
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            h = layer(t, h)
+            if i < last:
+                h = self.activation_fns[i](h)
+        return h
+
+
+class ODEfunc(nn.Module):
+    def __init__(self, diffeq, divergence_fn="approximate", residual=False, rademacher=False):
+        super().__init__()
+        assert divergence_fn in ("brute_force", "approximate")
+        if residual:
+            raise NotImplementedError("residual=True is not built into the HIP path (the reference's runs use False)")
+        self.diffeq = diffeq
+        self.residual = residual
+        self.rademacher = rademacher
+        self.divergence_fn = divergence_bf if divergence_fn == "brute_force" else divergence_approx
+        self.register_buffer("_num_evals", torch.tensor(0.0))
+        self._e = None
+
+    def before_odeint(self, e=None):
+        self._e = e
+        self._num_evals.fill_(0)
+
+    def num_evals(self):
+        return self._num_evals.item()
+
+    # -- description of the net for the kernels ------------------------------------------------------
+    def uses_hutchinson(self):
+        dims = self.diffeq.dims
+        if not self.training and dims[0] == 2:
+            return False  # the reference always uses the exact trace for 2-D data in eval mode
+        return self.divergence_fn is divergence_approx
+
+    def net_desc(self):
+        dims = self.diffeq.dims
+        hidden = dims[1:-1]
+        if len(set(hidden)) != 1:
+            raise NotImplementedError("the HIP path needs equal hidden widths (got %s)" % (hidden,))
+        return _native.net_desc(dims[0], hidden[0], len(hidden), self.uses_hutchinson())
+
+    def probe(self, like):
+        """Hutchinson noise: drawn once per solve (before_odeint resets it) and reused by the adjoint pass."""
+        if not self.uses_hutchinson():
+            return None
+        if self._e is None or self._e.shape != like.shape or self._e.device != like.device:
+            if self.rademacher:
+                self._e = (torch.randint(0, 2, like.shape, device=like.device) * 2 - 1).to(like)
+            else:
+                self._e = torch.randn_like(like)
+        return self._e
+
+    def forward(self, t, states):
+        """One evaluation (f, -div) on the device through the same kernel code the solvers inline."""
+        assert len(states) >= 2
+        y = states[0]
+        self._num_evals += 1
+        with torch.no_grad():
+            f, neg_div = _native.eval_field(self.net_desc(), self.diffeq.flat_parameters().detach(), float(t), y.detach(),
+                                            self.probe(y))
+        return (f, neg_div) + tuple(torch.zeros_like(s) for s in states[2:])

@@ -1,0 +1,125 @@
+/*
+ * cnf_hip.h -- C ABI of libcnf_hip.so: the MI355X (gfx950) FFJORD CNF hot path.
+ *
+ * The reference has no native code and no FFI: its hot path is Python calling torchdiffeq
+ *     odeint_adjoint(odefunc, (z, logpz), integration_times, atol=[a,a], rtol=[r,r], method=solver)
+ * from CNF.forward (ffjord/lib/layers/cnf.py, un-vendored submodule: /root/reference/.gitmodules:4-6;
+ * dependency pinned at /root/reference/requirements.txt:17; the only in-tree caller is
+ * /root/reference/model_plot.py:93-101).  The entry points below are what a binding for THAT call would
+ * bind: one typed call per solve instead of a Python callback per Runge-Kutta stage.
+ *
+ * Conventions
+ *   - every pointer is a BORROWED DEVICE pointer (fp32, contiguous row-major) unless marked "host";
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - the library never allocates device memory: the caller passes a workspace of
+ *     cnf_workspace_bytes() bytes (16-byte aligned) that the call zeroes and uses;
+ *   - return value 0 = enqueued; non-zero = rejected before launch, message in cnf_last_error();
+ *   - run-time failures of the integrator (step underflow, non-finite state, step limit) are
+ *     reported in CnfStats.status, which lives in device memory and is read by the caller after
+ *     it has synchronised the stream.  They mirror torchdiffeq's assertions
+ *     ("underflow in dt", "non-finite values in state `y`", "max_num_steps exceeded").
+ *
+ * Parameter vector `params` (cnf_param_count() floats): for each ConcatSquashLinear layer l in order,
+ *     _layer.weight (out x in, row-major) | _layer.bias (out) | _hyper_bias.weight (out)
+ *     | _hyper_gate.weight (out) | _hyper_gate.bias (out)
+ * i.e. torch.cat([p.reshape(-1) for p in odenet.parameters()]) of the reference's ODEnet
+ * (state_dict order recorded in SURVEY.md Appendix A).  Gradients come back in the same layout.
+ */
+#ifndef CNF_HIP_H
+#define CNF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ODEnet description: dim -> hidden x n_hidden -> dim, ConcatSquashLinear layers, tanh between layers.
+ * Replaces the Python object graph ODEfunc(ODEnet(...)).            */
+typedef struct CnfNetDesc {
+    int32_t dim;        /* data dimension d: 1, 2 or 16                                          */
+    int32_t hidden;     /* hidden width: 64                                                      */
+    int32_t n_hidden;   /* number of hidden layers: 3                                            */
+    int32_t divergence; /* 0 = brute force (exact trace, `divergence_bf`), 1 = Hutchinson
+                           (`divergence_approx`, probe `e` fixed for the whole solve)           */
+} CnfNetDesc;
+
+enum { CNF_SOLVER_DOPRI5 = 0, CNF_SOLVER_RK4 = 1 };
+enum { CNF_DIV_EXACT = 0, CNF_DIV_HUTCHINSON = 1 };
+
+/* Solver options: the keyword arguments of torchdiffeq.odeint (rtol, atol, method, options). */
+typedef struct CnfSolverOpts {
+    int32_t solver;      /* CNF_SOLVER_*                                                          */
+    float rtol, atol;    /* dopri5 tolerances (the same pair for z and logp, as CNF passes them)   */
+    float step_size;     /* rk4: options['step_size']; <= 0 means one step over [t0, t1]           */
+    int32_t tile_rows;   /* dopri5 step control: 0 = one step size for the whole batch (reference
+                            semantics); 16 = every 16-row tile controls its own step (throughput
+                            evaluation mode)                              */
+    int32_t max_steps;   /* dopri5 attempt limit per solve (0 = 1<<20)                            */
+} CnfSolverOpts;
+
+enum {
+    CNF_OK = 0,
+    CNF_ERR_DT_UNDERFLOW = 1, /* torchdiffeq: "underflow in dt"                                   */
+    CNF_ERR_NONFINITE = 2,    /* torchdiffeq: "non-finite values in state `y`"                    */
+    CNF_ERR_MAX_STEPS = 3,    /* torchdiffeq: max_num_steps exceeded                              */
+    CNF_ERR_SYNC_TIMEOUT = 4  /* a grid-wide reduction did not complete (should never happen)     */
+};
+
+/* Written by the kernels (device memory, 32 bytes).  For tile-local step control the counters are the
+ * maxima over tiles and `row_evals` is the sum over tiles of rows*evaluations (FLOP accounting). */
+typedef struct CnfStats {
+    int32_t status;      /* CNF_OK or CNF_ERR_*                                                   */
+    int32_t nfe;         /* function evaluations as the reference's ODEfunc._num_evals counts them */
+    int32_t n_accepted;
+    int32_t n_rejected;
+    float last_dt;
+    int32_t evals_run;   /* evaluations actually executed (the adjoint re-evaluates FSAL stages)   */
+    int64_t row_evals;   /* sum over rows of evaluations executed                                 */
+} CnfStats;
+
+/* Number of floats in `params` for this net; < 0 if the net is not supported. */
+int64_t cnf_param_count(const CnfNetDesc *net);
+
+/* Bytes of workspace the solve entry points need for a batch of `rows` (both directions). */
+size_t cnf_workspace_bytes(const CnfNetDesc *net, int64_t rows);
+
+/* Last error message of the calling thread (host string, never NULL). */
+const char *cnf_last_error(void);
+
+/* One evaluation of the dynamics, ODEfunc.forward(t, (y, logp)) -> (f, -div)   (SURVEY.md 8a a5).
+ *   z (rows x dim), e (rows x dim, Hutchinson probe or NULL), f_out (rows x dim), neg_div_out (rows). */
+int cnf_eval_field(const CnfNetDesc *net, const float *params, float t, const float *z, const float *e,
+                   int64_t rows, float *f_out, float *neg_div_out, void *stream);
+
+/* Forward solve: odeint(odefunc, (x, logp0), [t0, t1]) -> state at t1  (a7, a9, a11).
+ *   logp0 may be NULL (zeros).  t0 > t1 integrates backwards in time (reverse=True / sample_fn).  */
+int cnf_solve_fwd(const CnfNetDesc *net, const float *params, const float *x, const float *logp0,
+                  const float *e, int64_t rows, float t0, float t1, const CnfSolverOpts *opts,
+                  float *z_out, float *logp_out, void *workspace, size_t workspace_bytes,
+                  CnfStats *stats, void *stream);
+
+/* One evaluation of the adjoint's augmented dynamics (the closure `augmented_dynamics` inside
+ * OdeintAdjointMethod.backward, a10): given z, a_z, a_logp returns
+ *   f, -div, vjp_z = -(a_z . df/dz) + a_logp * d(div)/dz   (rows x dim)
+ *   vjp_params (cnf_param_count floats) = -(a . d(f,-div)/dtheta) summed over rows.               */
+int cnf_eval_aug(const CnfNetDesc *net, const float *params, float t, const float *z, const float *e,
+                 const float *a_z, const float *a_logp, int64_t rows, float *f_out, float *neg_div_out,
+                 float *vjp_z_out, float *vjp_params_out, void *workspace, size_t workspace_bytes,
+                 void *stream);
+
+/* Backward solve: OdeintAdjointMethod.backward for the single interval [t0, t1] (a10).
+ *   inputs : z1, logp1 = state at t1 saved by the forward; grad_z1, grad_logp1 = dL/d(state at t1)
+ *   outputs: grad_x, grad_logp0 = dL/d(state at t0); grad_params (overwritten).
+ *   Error control covers (z, logp) only, as the reference's length-2 tolerance lists imply.       */
+int cnf_solve_bwd(const CnfNetDesc *net, const float *params, const float *z1, const float *logp1,
+                  const float *e, const float *grad_z1, const float *grad_logp1, int64_t rows,
+                  float t0, float t1, const CnfSolverOpts *opts, float *grad_x, float *grad_logp0,
+                  float *grad_params, void *workspace, size_t workspace_bytes, CnfStats *stats,
+                  void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNF_HIP_H */

@@ -1,0 +1,116 @@
+"""CPU: host-side logic and the C-ABI boundary (no kernel is launched here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _helpers import GOLDEN, ROOT, fixture_state_dict
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from gan_flow_amd import _native
+    lib = _native.load_library()
+    header = open(os.path.join(ROOT, "include", "cnf_hip.h")).read()
+    declared = set(re.findall(r"\b(cnf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_native.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_param_count_and_workspace():
+    from gan_flow_amd import _native
+    lib = _native.load_library()
+    assert _native.param_count(_native.net_desc(1, 64, 3, False)) == 9092
+    assert _native.param_count(_native.net_desc(2, 64, 3, False)) == 9224
+    assert _native.param_count(_native.net_desc(16, 64, 3, True)) == 64 * 16 + 4 * 64 + 2 * (4096 + 256) + 16 * 64 + 64
+    with pytest.raises(_native.CnfError):
+        _native.param_count(_native.net_desc(2, 48, 3, False))
+    nd = _native.net_desc(2, 64, 3, False)
+    assert lib.cnf_workspace_bytes(ctypes.byref(nd), 2048) >= 16384 + 32 * 9224 * 4
+    assert lib.cnf_workspace_bytes(ctypes.byref(nd), 0) == 0
+
+
+def test_calls_are_rejected_before_launch_with_a_message():
+    from gan_flow_amd import _native
+    lib = _native.load_library()
+    nd = _native.net_desc(2, 64, 3, False)
+    opts = _native.make_opts("dopri5", 1e-5, 1e-5)
+    one = ctypes.c_void_p(16)
+    rc = lib.cnf_solve_fwd(ctypes.byref(nd), one, one, None, None, 0, 0.0, 0.5, ctypes.byref(opts), one, one, one, 1 << 20, one, None)
+    assert rc != 0 and b"rows must be positive" in lib.cnf_last_error()
+    rc = lib.cnf_solve_fwd(ctypes.byref(nd), one, one, None, None, 64, 0.5, 0.5, ctypes.byref(opts), one, one, one, 1 << 20, one, None)
+    assert rc != 0 and b"distinct" in lib.cnf_last_error()
+    rc = lib.cnf_solve_fwd(ctypes.byref(nd), one, one, None, None, 64, 0.0, 0.5, ctypes.byref(opts), one, one, one, 8, one, None)
+    assert rc != 0 and b"workspace too small" in lib.cnf_last_error()
+    rc = lib.cnf_solve_fwd(ctypes.byref(nd), one, one, None, None, 1 << 20, 0.0, 0.5, ctypes.byref(opts), one, one, one, 1 << 40, one, None)
+    assert rc != 0 and b"batch-global step control supports at most" in lib.cnf_last_error()
+    bad = _native.net_desc(3, 64, 3, False)
+    rc = lib.cnf_eval_field(ctypes.byref(bad), one, 0.0, one, None, 4, one, one, None)
+    assert rc != 0 and b"unsupported net" in lib.cnf_last_error()
+    hut = _native.net_desc(16, 64, 3, True)
+    rc = lib.cnf_eval_field(ctypes.byref(hut), one, 0.0, one, None, 4, one, one, None)
+    assert rc != 0 and b"probe" in lib.cnf_last_error()
+    with pytest.raises(_native.CnfError):
+        _native.make_opts("adams")
+
+
+def test_product_modules_keep_reference_names():
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.lib.layers import CNF, ODEfunc, ODEnet, SequentialFlow, ConcatSquashLinear, RegularizedODEfunc
+    m = gu_ffjord.build_model(1)
+    for which in ("unimodal", "multimodal"):
+        res = m.load_state_dict(fixture_state_dict(which), strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+    blk = m.chain[0]
+    assert isinstance(m, SequentialFlow) and isinstance(blk, CNF) and isinstance(blk.odefunc, RegularizedODEfunc)
+    assert isinstance(blk.odefunc.odefunc, ODEfunc) and isinstance(blk.odefunc.odefunc.diffeq, ODEnet)
+    assert isinstance(blk.odefunc.odefunc.diffeq.layers[0], ConcatSquashLinear)
+    assert (blk.solver, blk.atol, blk.rtol, blk.test_solver, blk.test_atol, blk.test_rtol) == ("dopri5", 1e-5, 1e-5, "dopri5", 1e-5, 1e-5)
+    assert blk.nreg == 0 and blk.solver_options == {} and isinstance(blk.sqrt_end_time, torch.nn.Parameter)
+    assert abs(float(blk.sqrt_end_time) ** 2 - 0.5) < 1e-6
+    fn = blk.odefunc.odefunc
+    assert fn.residual is False and fn.rademacher is False and float(fn._num_evals) == 1358.0
+    flat = fn.diffeq.flat_parameters()
+    assert flat.numel() == 9092
+    # layout documented in include/cnf_hip.h: layer 0 weight first, ..., layer 3 gate bias last
+    sd = fixture_state_dict("multimodal")
+    assert torch.equal(flat[:64], sd["chain.0.odefunc.odefunc.diffeq.layers.0._layer.weight"].reshape(-1))
+    assert float(flat[-1]) == float(sd["chain.0.odefunc.odefunc.diffeq.layers.3._hyper_gate.bias"])
+
+
+def test_hutchinson_selection_follows_reference_rules():
+    from gan_flow_amd import gu_ffjord
+    m = gu_ffjord.build_model(2, divergence_fn="approximate")
+    fn = m.chain[0].odefunc.odefunc
+    m.train()
+    assert fn.uses_hutchinson()
+    m.eval()
+    assert not fn.uses_hutchinson()        # 2-D data in eval mode: exact trace (ffjord odefunc "hack for 2D data")
+    m16 = gu_ffjord.build_model(16, divergence_fn="approximate").eval()
+    assert m16.chain[0].odefunc.odefunc.uses_hutchinson()
+
+
+def test_gu_sampler_matches_reference_vectors():
+    from gan_flow_amd.gu import GausUniffMixture
+    g = np.load(os.path.join(GOLDEN, "gu_samples.npz"))
+    cases = {"uni": dict(n_mixture=1, mean_dist=5, sigma=0.1, unif_intsect=5, unif_ratio=3),
+             "multi": dict(n_mixture=8, mean_dist=10, sigma=2, unif_intsect=1.5, unif_ratio=1.0)}
+    for name, kw in cases.items():
+        for ext in (0, 1):
+            m = GausUniffMixture(seed=7, extend_dim=bool(ext), **kw)
+            assert np.array_equal(m.get_sample(257).numpy(), g["%s_ext%d_a" % (name, ext)])
+            assert np.array_equal(m.get_sample(64).numpy(), g["%s_ext%d_b" % (name, ext)])
+        assert np.array_equal(m.density(g["%s_density_x" % name]), g["%s_density" % name])
+
+
+def test_w_distance_matches_scipy():
+    from scipy.stats import wasserstein_distance
+    from gan_flow_amd.util import w_distance
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(5000, 1, generator=g) * 3 + 1, torch.randn(5000, 1, generator=g)
+    assert w_distance(a, b) == np.round(wasserstein_distance(a.numpy().squeeze(), b.numpy().squeeze()), 4)
+    c = torch.randn(3000, 1, generator=g)
+    assert w_distance(a, c) == np.round(wasserstein_distance(a.numpy().squeeze(), c.numpy().squeeze()), 4)

@@ -1,0 +1,148 @@
+"""CPU: the oracle against everything the reference holds for this path:
+trained-checkpoint weights, the stored NFE counter, the analytic training density, Appendix C."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gan_flow_amd.gu import GausUniffMixture
+from _helpers import appendix_c, fixture_state_dict, oracle_fixture_model
+
+
+@pytest.mark.parametrize("which", ["unimodal", "multimodal"])
+def test_state_dict_names_match_checkpoint(which):
+    sd = fixture_state_dict(which)
+    m = oracle.build_cnf(1)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    assert abs(float(sd["chain.0.sqrt_end_time"]) - 0.70710677) < 1e-7
+    assert sum(v.numel() for k, v in sd.items() if "diffeq" in k) == 9092
+
+
+@pytest.mark.parametrize("which", ["unimodal", "multimodal"])
+def test_field_known_answers(which):
+    m = oracle_fixture_model(which)
+    fn = m.chain[0].odefunc.odefunc
+    for t, z, f_ref, dfdz_ref in appendix_c()["field"][which]:
+        f, neg_div = fn(torch.tensor(t), (torch.tensor([[z]]), torch.zeros(1, 1)))
+        assert abs(f.item() - f_ref) <= 1e-5 * max(1.0, abs(f_ref))
+        assert abs(-neg_div.item() - dfdz_ref) <= 1e-5 * max(1.0, abs(dfdz_ref))
+
+
+def test_stored_nfe_unimodal_is_reproduced_exactly():
+    """The checkpoint's `_num_evals` (116 = 2 + 6*(15 accepted + 4 rejected)) was left by a 10 000-row sampling solve
+    (model_plot.py:97); dopri5(1e-5) on 10 000 N(0,1) draws must give the same count."""
+    m = oracle_fixture_model("unimodal")
+    sample_fn, _ = oracle.get_transforms(m)
+    for seed in (0, 1):
+        z = torch.randn(10000, 1, generator=torch.Generator().manual_seed(seed))
+        with torch.no_grad():
+            sample_fn(z)
+        st = m.chain[0].stats["forward"]
+        assert m.chain[0].num_evals() == appendix_c()["stored_nfe"]["unimodal"]
+        assert (st["n_accepted"], st["n_rejected"]) == (15, 4)
+
+
+def test_stored_nfe_multimodal_is_close():
+    m = oracle_fixture_model("multimodal")
+    sample_fn, _ = oracle.get_transforms(m)
+    z = torch.randn(10000, 1, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        sample_fn(z)
+    assert abs(m.chain[0].num_evals() - appendix_c()["stored_nfe"]["multimodal"]) <= 60  # draw-dependent (stiff field)
+
+
+@pytest.mark.parametrize("which", ["unimodal", "multimodal"])
+def test_solves_match_tight_reference(which):
+    kat = appendix_c()
+    m = oracle_fixture_model(which)
+    sample_fn, density_fn = oracle.get_transforms(m)
+    x = torch.tensor(kat["forward"][which]["x"]).reshape(-1, 1)
+    with torch.no_grad():
+        z, dl = density_fn(x, torch.zeros_like(x))
+    bulk = torch.tensor(kat["forward"][which]["z"]).abs() < 4
+    tol = 5e-4 if which == "unimodal" else 3e-3   # fp32 dopri5 at 1e-5 with a 5-row batch norm; stiff multimodal field
+    assert (z.ravel() - torch.tensor(kat["forward"][which]["z"])).abs()[bulk].max() < tol
+    logpx = (oracle.standard_normal_logprob(z) - dl).ravel()
+    assert (logpx - torch.tensor(kat["forward"][which]["logpx"])).abs()[bulk].max() < tol
+    zz = torch.tensor(kat["reverse"][which]["z"], dtype=torch.float32).reshape(-1, 1)
+    with torch.no_grad():
+        xx, dl2 = sample_fn(zz, torch.zeros_like(zz))
+    scale = 1.0 if which == "unimodal" else 80.0
+    assert (xx.ravel() - torch.tensor(kat["reverse"][which]["x"])).abs().max() < 1e-3 * scale
+    assert (dl2.ravel() - torch.tensor(kat["reverse"][which]["delta_logp"])).abs().max() < (2e-3 if which == "unimodal" else 5e-3)
+
+
+@pytest.mark.parametrize("which", ["unimodal", "multimodal"])
+def test_float64_tight_solves_match_appendix_c(which):
+    """Same weights, float64 state, tolerances 1e-10: the oracle must land on the DOP853 values to ~1e-6."""
+    kat = appendix_c()
+    m = oracle_fixture_model(which, torch.float64)
+    m.chain[0].test_atol = m.chain[0].test_rtol = 1e-10
+    sample_fn, density_fn = oracle.get_transforms(m)
+    x = torch.tensor(kat["forward"][which]["x"], dtype=torch.float64).reshape(-1, 1)
+    with torch.no_grad():
+        z, dl = density_fn(x, torch.zeros_like(x))
+    assert (z.ravel() - torch.tensor(kat["forward"][which]["z"], dtype=torch.float64)).abs().max() < 2e-6
+    assert (dl.ravel() - torch.tensor(kat["forward"][which]["delta_logp"], dtype=torch.float64)).abs().max() < 2e-6
+    zz = torch.tensor(kat["reverse"][which]["z"], dtype=torch.float64).reshape(-1, 1)
+    with torch.no_grad():
+        xx, dl2 = sample_fn(zz, torch.zeros_like(zz))
+    assert (xx.ravel() - torch.tensor(kat["reverse"][which]["x"], dtype=torch.float64)).abs().max() < 2e-5
+    assert (dl2.ravel() - torch.tensor(kat["reverse"][which]["delta_logp"], dtype=torch.float64)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("which,lo,hi,kw", [
+    ("unimodal", 3.5, 6.5, dict(n_mixture=1, mean_dist=5, sigma=0.1, unif_intsect=5, unif_ratio=3)),
+    ("multimodal", -10.0, 100.0, dict(n_mixture=8, mean_dist=10, sigma=2, unif_intsect=1.5, unif_ratio=1.0)),
+])
+def test_model_density_normalises_and_matches_training_density(which, lo, hi, kw):
+    m = oracle_fixture_model(which)
+    _, density_fn = oracle.get_transforms(m)
+    xs = torch.linspace(lo, hi, 2001).reshape(-1, 1)
+    with torch.no_grad():
+        z, dl = density_fn(xs, torch.zeros_like(xs))
+    p = torch.exp(oracle.standard_normal_logprob(z) - dl).ravel().double().numpy()
+    grid = xs.detach().ravel().double().numpy()
+    integral = np.trapz(p, grid)
+    assert abs(integral - 1.0) < 2e-3
+    true = GausUniffMixture(**kw).density(grid)
+    l1 = np.trapz(np.abs(p - true), grid)
+    assert l1 < 0.15      # SURVEY probe P1: 0.034 (unimodal), 0.109 (multimodal)
+
+
+def test_rk4_fixed_grid_matches_dopri5():
+    m = oracle_fixture_model("unimodal")
+    x = torch.linspace(4.6, 5.4, 9).reshape(-1, 1)
+    with torch.no_grad():
+        z_ref, l_ref = m(x, torch.zeros_like(x))
+        blk = m.chain[0]
+        blk.test_solver = "rk4"
+        z4, l4 = oracle.odeint(blk.odefunc, (x, torch.zeros_like(x)), torch.tensor([0.0, 0.5]), method="rk4",
+                               options=dict(step_size=0.01))
+    assert (z4[1] - z_ref).abs().max() < 1e-3 and (l4[1] - l_ref).abs().max() < 1e-3
+
+
+def test_adjoint_gradients_match_autograd_through_unrolled_rk4():
+    """Appendix D has no reference artefact: check the adjoint against plain backprop through a fine fixed grid."""
+    torch.manual_seed(0)
+    m = oracle.build_cnf(2).double()
+    x = torch.randn(8, 2, dtype=torch.float64) * 0.5
+    blk = m.chain[0]
+    blk.atol = blk.rtol = 1e-9
+
+    def loss_of(z, dl):
+        return -(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()
+
+    m.train()
+    z, dl = m(x, torch.zeros(8, 1, dtype=torch.float64))
+    m.zero_grad()
+    loss_of(z, dl).backward()
+    g_adj = torch.cat([p.grad.reshape(-1) for p in blk.odefunc.parameters()])
+    m.zero_grad()
+    zs, ls = oracle.odeint(blk.odefunc, (x, torch.zeros(8, 1, dtype=torch.float64)),
+                           torch.tensor([0.0, 0.5], dtype=torch.float64), method="rk4", options=dict(step_size=0.005))
+    loss_of(zs[1], ls[1]).backward()
+    g_bp = torch.cat([p.grad.reshape(-1) for p in blk.odefunc.parameters()])
+    assert (g_adj - g_bp).abs().max() / g_bp.abs().max() < 1e-5
