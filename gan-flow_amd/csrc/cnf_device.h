@@ -360,8 +360,9 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
 
 // tile-local variant: the 16 rows of this wave are the whole control group
 __device__ __forceinline__ void wave_allreduce4(double (&v)[4]) {
+    // only quarter 0 carries counted rows: reduce its 16 lanes, then hand lane 0's total to every lane
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = row16_sum(v[i]);
+    for (int i = 0; i < 4; ++i) v[i] = __shfl(row16_sum(v[i]), 0);
 }
 
 }  // namespace cnf
