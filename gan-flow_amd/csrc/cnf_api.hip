@@ -172,7 +172,7 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
     a.slab = (float*)((char*)workspace + kGranBytes);
     a.grad_params = vjp_params_out;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t err = hipMemsetAsync(workspace, 0, kGranBytes, s);
+    hipError_t err = hipMemsetAsync(workspace, 0, need, s);   // granules + per-workgroup gradient slabs
     if (err == hipSuccess) err = cnf::launch_eval_aug(net->dim, hutch, a, t, z, a_z, a_logp, f_out, neg_div_out, vjp_z_out, s);
     if (err != hipSuccess) return fail("cnf_eval_aug: launch failed: %s", hipGetErrorString(err));
     return 0;
@@ -200,7 +200,7 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     a.grad_logp0 = grad_logp0;
     a.grad_params = grad_params;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t err = hipMemsetAsync(workspace, 0, kGranBytes, s);
+    hipError_t err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // granules + gradient slabs
     if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
     if (err == hipSuccess) err = cnf::launch_solve_bwd(net->dim, hutch, a, s);
     if (err != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(err));

@@ -29,23 +29,20 @@ constexpr int kRowsPerWG = kNW * kRows;
 constexpr int kMaxWG = 256;        // grid-wide reductions need every workgroup resident: <= 1 per CU
 
 // ---- flat parameter layout (include/cnf_hip.h) -------------------------------------------------
+// Offsets are closed forms (no arrays): a runtime-indexed private array would be promoted to LDS by the compiler.
 struct ParamLayout {
-    int w[4], b[4], hb[4], wg[4], bg[4];
-    int total;
+    int D, H, total;
+    __host__ __device__ int din(int l) const { return l == 0 ? D : H; }
+    __host__ __device__ int dout(int l) const { return l == 3 ? D : H; }
+    __host__ __device__ int w(int l) const { return l == 0 ? 0 : (H * D + 4 * H) + (l - 1) * (H * H + 4 * H); }
+    __host__ __device__ int b(int l) const { return w(l) + dout(l) * din(l); }
+    __host__ __device__ int hb(int l) const { return b(l) + dout(l); }
+    __host__ __device__ int wg(int l) const { return b(l) + 2 * dout(l); }
+    __host__ __device__ int bg(int l) const { return b(l) + 3 * dout(l); }
 };
 __host__ __device__ inline ParamLayout make_layout(int D, int H) {
-    ParamLayout L{};
-    const int din[4] = {D, H, H, H};
-    const int dout[4] = {H, H, H, D};
-    int off = 0;
-    for (int l = 0; l < 4; ++l) {
-        L.w[l] = off;  off += dout[l] * din[l];
-        L.b[l] = off;  off += dout[l];
-        L.hb[l] = off; off += dout[l];
-        L.wg[l] = off; off += dout[l];
-        L.bg[l] = off; off += dout[l];
-    }
-    L.total = off;
+    ParamLayout L{D, H, 0};
+    L.total = L.bg(3) + D;
     return L;
 }
 
@@ -121,26 +118,26 @@ __device__ inline void stage_net(NetLds<D>& n, const float* __restrict__ p, int 
         const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
         const int row = 16 * (tt >> 2) + (lane & 15);
         const int col = 16 * (tt & 3) + 4 * (lane >> 4) + r;
-        img[idx] = p[L.w[1 + l] + row * kH + col];
+        img[idx] = p[L.w(1 + l) + row * kH + col];
     }
     for (int idx = tid; idx < D * kH; idx += kThreads) {
         const int m = idx / kH, i = idx % kH;
-        n.w1[m][i] = p[L.w[0] + i * D + m];
-        n.w4[m][i] = p[L.w[3] + m * kH + i];
+        n.w1[m][i] = p[L.w(0) + i * D + m];
+        n.w4[m][i] = p[L.w(3) + m * kH + i];
     }
     for (int idx = tid; idx < 3 * kH; idx += kThreads) {
         const int l = idx / kH, i = idx % kH;
-        n.vec[l][0][i] = p[L.b[l] + i];
-        n.vec[l][1][i] = p[L.hb[l] + i];
-        n.vec[l][2][i] = p[L.wg[l] + i];
-        n.vec[l][3][i] = p[L.bg[l] + i];
+        n.vec[l][0][i] = p[L.b(l) + i];
+        n.vec[l][1][i] = p[L.hb(l) + i];
+        n.vec[l][2][i] = p[L.wg(l) + i];
+        n.vec[l][3][i] = p[L.bg(l) + i];
     }
     if (tid < 16) {
         const bool in = tid < D;
-        n.vec4[0][tid] = in ? p[L.b[3] + tid] : 0.f;
-        n.vec4[1][tid] = in ? p[L.hb[3] + tid] : 0.f;
-        n.vec4[2][tid] = in ? p[L.wg[3] + tid] : 0.f;
-        n.vec4[3][tid] = in ? p[L.bg[3] + tid] : 0.f;
+        n.vec4[0][tid] = in ? p[L.b(3) + tid] : 0.f;
+        n.vec4[1][tid] = in ? p[L.hb(3) + tid] : 0.f;
+        n.vec4[2][tid] = in ? p[L.wg(3) + tid] : 0.f;
+        n.vec4[3][tid] = in ? p[L.bg(3) + tid] : 0.f;
     }
 }
 
