@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- FFJORD CNF training throughput on MI355X (BASELINE.json metric: CNF train iters/s, B=2048, d=2).
+
+One "step" = one full training iteration of `gu_maf --gu_num 8` (BASELINE configs[1]): forward dopri5 solve of
+the CNF on a (2048, 2) batch, negative log-likelihood, adjoint backward solve, Adam update.  Inputs are
+synthetic batches of the gu_num=8 Gaussian-uniform mixture, generated before the timed region and resident in HBM;
+weights are nn.Linear default init under torch.manual_seed(1 + rank).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): training does not shard (batch-global step control),
+so every rank runs an independent trial -- the reference's own multi-GPU use (one gu_num trial per cuda:i) -- and
+`value` is the total iterations/s over ranks ("weak").  The part of the path that does shard, large-N
+log-likelihood evaluation with one RCCL all-reduce, is timed next to it and reported under "eval".
+
+Extra objects on the JSON line: "roofline" (dominant kernel = the adjoint solve, MFMA fp32 peak), "cpu_baseline"
+(the oracle, i.e. the PyTorch-CPU restatement of the reference path, timed on the host cores on the same batches),
+"late_training" (same step on the stiff trained gu_num=8 field, where NFE is ~100x higher) and "eval".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+F_EVAL_D2 = 2 * 8448 + 2 * 2 * (8448 - 2 * 64)   # 50 176 FLOP per sample-eval (d=2, H=64^3, exact div)
+F_EVAL_D1 = 2 * 8320 + 2 * 1 * (8320 - 1 * 64)   # 33 152 (d=1 fixtures)
+PEAK_FP32_MATRIX_TFLOPS = 157.3                  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=2048)
+    p.add_argument("--eval-rows", type=int, default=1 << 20, help="rows of the sharded log-likelihood evaluation")
+    p.add_argument("--late-steps", type=int, default=3)
+    p.add_argument("--cpu-iters", type=int, default=12, help="oracle iterations timed for cpu_baseline (rank 0, N=1)")
+    p.add_argument("--no-extras", action="store_true", help="only the headline measurement")
+    return p.parse_args()
+
+
+def embed_trained_multimodal(model):
+    """Late-training stand-in: the reference's trained gu_num=8 weights (d=1 checkpoint fixture) placed in the d=2
+    net with the nuisance coordinate decoupled (zero column / zero row): same stiff field, NFE ~1.3-1.7k."""
+    import numpy as np
+    a = np.load(os.path.join(ROOT, "tests", "golden", "ffjord_multimodal.npz"))
+    sd = model.state_dict()
+    for k in sd:
+        if k not in a.files:
+            continue
+        src = torch.from_numpy(a[k])
+        if k.endswith("layers.0._layer.weight"):
+            sd[k].zero_()
+            sd[k][:, :1] = src
+        elif ".layers.3." in k:
+            sd[k].zero_()
+            if src.dim() == 2 and src.shape[1] == 64:
+                sd[k][:1, :] = src
+            elif src.dim() == 2:
+                sd[k][:1, :] = src
+            else:
+                sd[k][:1] = src
+        else:
+            sd[k].copy_(src)
+    model.load_state_dict(sd)
+    return model
+
+
+def train_step(model, opt, x, gu_ffjord):
+    opt.zero_grad(set_to_none=True)
+    loss = gu_ffjord.compute_loss(model, x)
+    loss.backward()
+    opt.step()
+    blk = model.chain[0]
+    return loss, blk.last_stats["forward"], blk.last_stats["backward"]
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the CNF path is a HIP kernel with no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gan_flow_amd import _native, gu_ffjord, parallel_eval
+    from gan_flow_amd.gu import make_gu
+    _native.load_library()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    # ---------------------------------------------------------------- headline: training iterations/s
+    data = make_gu(8, device="cpu", seed=1 + rank, extend_dim=True)
+    batches = [data.get_sample(args.batch).to(dev) for _ in range(args.warmup + args.steps)]
+    torch.manual_seed(1 + rank)
+    model = gu_ffjord.build_model(2).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    for x in batches[:args.warmup]:
+        train_step(model, opt, x, gu_ffjord)
+    nfe_f = nfe_b = 0
+    barrier()
+    t0 = time.perf_counter()
+    for x in batches[args.warmup:]:
+        _, sf, sb = train_step(model, opt, x, gu_ffjord)
+        nfe_f += sf.nfe
+        nfe_b += sb.nfe
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    value = world * args.steps / elapsed
+    out = {
+        "metric": "CNF train iters/s (B=2048, d=2)", "value": round(value, 3), "unit": "iters/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "FFJORD CNF gu_maf --gu_num 8, B=%d, d=2, ODEnet 2-64-64-64-2 concatsquash/tanh, dopri5 "
+                               "rtol=atol=1e-5, T=0.5, exact divergence, adjoint backward, Adam; weights from seed-1 "
+                               "init (first %d iterations of training)" % (args.batch, args.warmup + args.steps),
+                   "global_batch": args.batch * world, "parallelism": "independent trial per GPU (replicas only)",
+                   "mean_nfe_forward": round(nfe_f / args.steps, 1), "mean_nfe_backward": round(nfe_b / args.steps, 1)},
+    }
+
+    if not args.no_extras:
+        # ------------------------------------------------------------ roofline of the dominant kernel (rank 0)
+        if rank == 0:
+            blk = model.chain[0]
+            fn = blk.odefunc.odefunc
+            net = fn.net_desc()
+            params = fn.diffeq.flat_parameters().detach()
+            opts = _native.make_opts("dopri5", blk.rtol, blk.atol)
+            T = float(blk.sqrt_end_time.detach() ** 2)
+            x = batches[-1]
+            z1, l1, _ = _native.solve_fwd(net, params, x, None, 0.0, T, opts)
+            gz, gl = z1 / args.batch, torch.full_like(l1, 1.0 / args.batch)
+            reps = 20
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in ev:   # events on the stream the kernels are launched on (torch's current stream)
+                a.record()
+                st = _native.solve_bwd(net, params, z1, l1, gz, gl, 0.0, T, opts)[3]
+                b.record()
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in ev) / reps
+            st = _native.Stats(st)
+            flops = args.batch * st.nfe * 3 * F_EVAL_D2
+            achieved = flops / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "dopri5_bwd_kernel<2,false>", "achieved": round(achieved, 4),
+                               "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5),
+                               "traffic": None, "launch_ms": round(ms, 4), "nfe": st.nfe, "evals_run": st.evals_run,
+                               "flop_per_launch": flops}
+
+        # ------------------------------------------------------------ late-training step (stiff trained field)
+        torch.manual_seed(1 + rank)
+        late = embed_trained_multimodal(gu_ffjord.build_model(2)).to(dev).train()
+        lopt = torch.optim.Adam(late.parameters(), lr=1e-5, weight_decay=1e-5)
+        train_step(late, lopt, batches[0], gu_ffjord)
+        barrier()
+        t0 = time.perf_counter()
+        lf = lb = 0
+        for i in range(args.late_steps):
+            _, sf, sb = train_step(late, lopt, batches[1 + i], gu_ffjord)
+            lf += sf.nfe
+            lb += sb.nfe
+        barrier()
+        lel = max_over_ranks(time.perf_counter() - t0)
+        out["late_training"] = {"value": round(world * args.late_steps / lel, 4), "unit": "iters/s",
+                                "ms_per_step": round(1e3 * lel / args.late_steps, 2),
+                                "mean_nfe_forward": round(lf / args.late_steps, 1), "mean_nfe_backward": round(lb / args.late_steps, 1),
+                                "workload": "same step on the reference's trained gu_num=8 field (checkpoint weights embedded in d=2)"}
+
+        # ------------------------------------------------------------ sharded log-likelihood evaluation (config 3)
+        import numpy as np
+        a = np.load(os.path.join(ROOT, "tests", "golden", "ffjord_multimodal.npz"))
+        em = gu_ffjord.build_model(1)
+        em.load_state_dict({k: torch.from_numpy(a[k]) for k in a.files})
+        em = em.to(dev).eval()
+        for b in em.chain:
+            b.tile_rows = 16
+        lo, hi = parallel_eval.shard_bounds(args.eval_rows, rank, world)
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        n_loc = hi - lo
+        half = n_loc // 2
+        comp = torch.randint(0, 8, (half,), generator=g, device=dev).float() * 10 + 10
+        xs = torch.cat([comp + (torch.rand(half, generator=g, device=dev) * 6 - 3),
+                        45 + 23 * torch.randn(n_loc - half, generator=g, device=dev)]).reshape(-1, 1)
+        with torch.no_grad():
+            parallel_eval.sharded_mean_log_likelihood(lambda v: parallel_eval.model_log_prob(em, v), xs[: 1 << 14])
+            barrier()
+            t0 = time.perf_counter()
+            mean_lp, rows = parallel_eval.sharded_mean_log_likelihood(lambda v: parallel_eval.model_log_prob(em, v), xs)
+            barrier()
+        eel = max_over_ranks(time.perf_counter() - t0)
+        out["eval"] = {"value": round(rows / eel, 1), "unit": "samples/s", "rows": rows, "scaling": "strong",
+                       "mean_log_likelihood": round(mean_lp, 5),
+                       "workload": "log-likelihood of %d synthetic points under the trained gu_num=8 CNF (d=1 checkpoint), "
+                                   "tile-local dopri5 1e-5, batch-sharded, one all-reduce of 2 x f64" % rows}
+
+        # ------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+        if rank == 0 and world == 1 and args.cpu_iters > 0:
+            import oracle
+            ncores = min(16, os.cpu_count() or 1)
+            torch.set_num_threads(ncores)
+            torch.manual_seed(1)
+            om = oracle.build_cnf(2).train()
+            oopt = torch.optim.Adam(om.parameters(), lr=1e-3, weight_decay=1e-5)
+            cpu_batches = [b.cpu() for b in batches[: args.cpu_iters + 1]]
+
+            def ostep(x):
+                oopt.zero_grad(set_to_none=True)
+                z, dl = om(x, torch.zeros(x.shape[0], 1))
+                loss = -(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()
+                loss.backward()
+                oopt.step()
+
+            ostep(cpu_batches[0])
+            t0 = time.perf_counter()
+            for x in cpu_batches[1:]:
+                ostep(x)
+            cel = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(args.cpu_iters / cel, 4), "unit": "iters/s", "cores": ncores, "kind": "port",
+                                   "sample": "%d training iterations of the same workload (same seed-1 init, same first batches) "
+                                             "on the PyTorch-CPU oracle, torch.set_num_threads(%d)" % (args.cpu_iters, ncores)}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
