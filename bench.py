@@ -42,7 +42,8 @@ def parse():
     p.add_argument("--eval-rows", type=int, default=1 << 20, help="rows of the sharded log-likelihood evaluation")
     p.add_argument("--late-steps", type=int, default=3)
     p.add_argument("--cpu-iters", type=int, default=12, help="oracle iterations timed for cpu_baseline (rank 0, N=1)")
-    p.add_argument("--no-extras", action="store_true", help="only the headline measurement")
+    p.add_argument("--extras", type=str, default="roofline,late,eval,cpu",
+                   help="comma list of the additional measurements to run: roofline, late, eval, cpu ('' = none)")
     return p.parse_args()
 
 
@@ -139,110 +140,134 @@ def main():
                    "mean_nfe_forward": round(nfe_f / args.steps, 1), "mean_nfe_backward": round(nfe_b / args.steps, 1)},
     }
 
-    if not args.no_extras:
-        # ------------------------------------------------------------ roofline of the dominant kernel (rank 0)
-        if rank == 0:
-            blk = model.chain[0]
-            fn = blk.odefunc.odefunc
-            net = fn.net_desc()
-            params = fn.diffeq.flat_parameters().detach()
-            opts = _native.make_opts("dopri5", blk.rtol, blk.atol)
-            T = float(blk.sqrt_end_time.detach() ** 2)
-            x = batches[-1]
-            z1, l1, _ = _native.solve_fwd(net, params, x, None, 0.0, T, opts)
-            gz, gl = z1 / args.batch, torch.full_like(l1, 1.0 / args.batch)
-            reps = 20
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-            for a, b in ev:   # events on the stream the kernels are launched on (torch's current stream)
-                a.record()
-                st = _native.solve_bwd(net, params, z1, l1, gz, gl, 0.0, T, opts)[3]
-                b.record()
-            torch.cuda.synchronize()
-            ms = sum(a.elapsed_time(b) for a, b in ev) / reps
-            st = _native.Stats(st)
-            flops = args.batch * st.nfe * 3 * F_EVAL_D2
-            achieved = flops / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "dopri5_bwd_kernel<2,false>", "achieved": round(achieved, 4),
-                               "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5),
-                               "traffic": None, "launch_ms": round(ms, 4), "nfe": st.nfe, "evals_run": st.evals_run,
-                               "flop_per_launch": flops}
-
-        # ------------------------------------------------------------ late-training step (stiff trained field)
-        torch.manual_seed(1 + rank)
-        late = embed_trained_multimodal(gu_ffjord.build_model(2)).to(dev).train()
-        lopt = torch.optim.Adam(late.parameters(), lr=1e-5, weight_decay=1e-5)
-        train_step(late, lopt, batches[0], gu_ffjord)
-        barrier()
-        t0 = time.perf_counter()
-        lf = lb = 0
-        for i in range(args.late_steps):
-            _, sf, sb = train_step(late, lopt, batches[1 + i], gu_ffjord)
-            lf += sf.nfe
-            lb += sb.nfe
-        barrier()
-        lel = max_over_ranks(time.perf_counter() - t0)
-        out["late_training"] = {"value": round(world * args.late_steps / lel, 4), "unit": "iters/s",
-                                "ms_per_step": round(1e3 * lel / args.late_steps, 2),
-                                "mean_nfe_forward": round(lf / args.late_steps, 1), "mean_nfe_backward": round(lb / args.late_steps, 1),
-                                "workload": "same step on the reference's trained gu_num=8 field (checkpoint weights embedded in d=2)"}
-
-        # ------------------------------------------------------------ sharded log-likelihood evaluation (config 3)
-        import numpy as np
-        a = np.load(os.path.join(ROOT, "tests", "golden", "ffjord_multimodal.npz"))
-        em = gu_ffjord.build_model(1)
-        em.load_state_dict({k: torch.from_numpy(a[k]) for k in a.files})
-        em = em.to(dev).eval()
-        for b in em.chain:
-            b.tile_rows = 16
-        lo, hi = parallel_eval.shard_bounds(args.eval_rows, rank, world)
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        n_loc = hi - lo
-        half = n_loc // 2
-        comp = torch.randint(0, 8, (half,), generator=g, device=dev).float() * 10 + 10
-        xs = torch.cat([comp + (torch.rand(half, generator=g, device=dev) * 6 - 3),
-                        45 + 23 * torch.randn(n_loc - half, generator=g, device=dev)]).reshape(-1, 1)
-        with torch.no_grad():
-            parallel_eval.sharded_mean_log_likelihood(lambda v: parallel_eval.model_log_prob(em, v), xs[: 1 << 14])
-            barrier()
-            t0 = time.perf_counter()
-            mean_lp, rows = parallel_eval.sharded_mean_log_likelihood(lambda v: parallel_eval.model_log_prob(em, v), xs)
-            barrier()
-        eel = max_over_ranks(time.perf_counter() - t0)
-        out["eval"] = {"value": round(rows / eel, 1), "unit": "samples/s", "rows": rows, "scaling": "strong",
-                       "mean_log_likelihood": round(mean_lp, 5),
-                       "workload": "log-likelihood of %d synthetic points under the trained gu_num=8 CNF (d=1 checkpoint), "
-                                   "tile-local dopri5 1e-5, batch-sharded, one all-reduce of 2 x f64" % rows}
-
-        # ------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
-        if rank == 0 and world == 1 and args.cpu_iters > 0:
-            import oracle
-            ncores = min(16, os.cpu_count() or 1)
-            torch.set_num_threads(ncores)
-            torch.manual_seed(1)
-            om = oracle.build_cnf(2).train()
-            oopt = torch.optim.Adam(om.parameters(), lr=1e-3, weight_decay=1e-5)
-            cpu_batches = [b.cpu() for b in batches[: args.cpu_iters + 1]]
-
-            def ostep(x):
-                oopt.zero_grad(set_to_none=True)
-                z, dl = om(x, torch.zeros(x.shape[0], 1))
-                loss = -(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()
-                loss.backward()
-                oopt.step()
-
-            ostep(cpu_batches[0])
-            t0 = time.perf_counter()
-            for x in cpu_batches[1:]:
-                ostep(x)
-            cel = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": round(args.cpu_iters / cel, 4), "unit": "iters/s", "cores": ncores, "kind": "port",
-                                   "sample": "%d training iterations of the same workload (same seed-1 init, same first batches) "
-                                             "on the PyTorch-CPU oracle, torch.set_num_threads(%d)" % (args.cpu_iters, ncores)}
+    extras = set(e for e in args.extras.split(",") if e)
+    ctx = dict(args=args, world=world, rank=rank, dev=dev, batches=batches, model=model, barrier=barrier,
+               max_over_ranks=max_over_ranks)
+    if "roofline" in extras and rank == 0:
+        out["roofline"] = measure_roofline(ctx)
+    if "late" in extras:
+        out["late_training"] = measure_late(ctx)
+    if "eval" in extras:
+        out["eval"] = measure_eval(ctx)
+    if "cpu" in extras and rank == 0 and world == 1 and args.cpu_iters > 0:
+        out["cpu_baseline"] = measure_cpu(ctx)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_roofline(ctx):
+    """Dominant kernel = the adjoint solve.  achieved = algorithmic FLOP per launch (rows x NFE x 3 x F_eval, NFE as the
+    reference counts it) / mean launch duration, HIP events on the launch stream (torch's current stream)."""
+    from gan_flow_amd import _native
+    args, model, batches = ctx["args"], ctx["model"], ctx["batches"]
+    blk = model.chain[0]
+    fn = blk.odefunc.odefunc
+    net = fn.net_desc()
+    params = fn.diffeq.flat_parameters().detach()
+    opts = _native.make_opts("dopri5", blk.rtol, blk.atol)
+    T = float(blk.sqrt_end_time.detach() ** 2)
+    x = batches[-1]
+    z1, l1, _ = _native.solve_fwd(net, params, x, None, 0.0, T, opts)
+    gz, gl = z1 / args.batch, torch.full_like(l1, 1.0 / args.batch)
+    reps = 20
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        st = _native.solve_bwd(net, params, z1, l1, gz, gl, 0.0, T, opts)[3]
+        b.record()
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in ev) / reps
+    st = _native.Stats(st)
+    flops = args.batch * st.nfe * 3 * F_EVAL_D2
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "dopri5_bwd_kernel<2,false>", "achieved": round(achieved, 4),
+            "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5),
+            "traffic": None, "launch_ms": round(ms, 4), "nfe": st.nfe, "evals_run": st.evals_run, "flop_per_launch": flops}
+
+
+def measure_late(ctx):
+    """The same training step on the stiff trained gu_num=8 field (NFE ~1.7k per solve)."""
+    from gan_flow_amd import gu_ffjord
+    args, world, rank, dev, batches = ctx["args"], ctx["world"], ctx["rank"], ctx["dev"], ctx["batches"]
+    torch.manual_seed(1 + rank)
+    late = embed_trained_multimodal(gu_ffjord.build_model(2)).to(dev).train()
+    lopt = torch.optim.Adam(late.parameters(), lr=1e-5, weight_decay=1e-5)
+    train_step(late, lopt, batches[0], gu_ffjord)
+    ctx["barrier"]()
+    t0 = time.perf_counter()
+    lf = lb = 0
+    for i in range(args.late_steps):
+        _, sf, sb = train_step(late, lopt, batches[1 + i], gu_ffjord)
+        lf += sf.nfe
+        lb += sb.nfe
+    ctx["barrier"]()
+    lel = ctx["max_over_ranks"](time.perf_counter() - t0)
+    return {"value": round(world * args.late_steps / lel, 4), "unit": "iters/s", "ms_per_step": round(1e3 * lel / args.late_steps, 2),
+            "mean_nfe_forward": round(lf / args.late_steps, 1), "mean_nfe_backward": round(lb / args.late_steps, 1),
+            "workload": "same step on the reference's trained gu_num=8 field (checkpoint weights embedded in d=2)"}
+
+
+def measure_eval(ctx):
+    """BASELINE config 3 (bounded): log-likelihood of eval_rows synthetic points, batch-sharded, one all-reduce."""
+    import numpy as np
+    from gan_flow_amd import gu_ffjord, parallel_eval
+    args, world, rank, dev = ctx["args"], ctx["world"], ctx["rank"], ctx["dev"]
+    a = np.load(os.path.join(ROOT, "tests", "golden", "ffjord_multimodal.npz"))
+    em = gu_ffjord.build_model(1)
+    em.load_state_dict({k: torch.from_numpy(a[k]) for k in a.files})
+    em = em.to(dev).eval()
+    for b in em.chain:
+        b.tile_rows = 16
+    lo, hi = parallel_eval.shard_bounds(args.eval_rows, rank, world)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_loc = hi - lo
+    half = n_loc // 2
+    comp = torch.randint(0, 8, (half,), generator=g, device=dev).float() * 10 + 10
+    xs = torch.cat([comp + (torch.rand(half, generator=g, device=dev) * 6 - 3),
+                    45 + 23 * torch.randn(n_loc - half, generator=g, device=dev)]).reshape(-1, 1)
+    lp = lambda v: parallel_eval.model_log_prob(em, v)  # noqa: E731
+    with torch.no_grad():
+        parallel_eval.sharded_mean_log_likelihood(lp, xs[: 1 << 14])
+        ctx["barrier"]()
+        t0 = time.perf_counter()
+        mean_lp, rows = parallel_eval.sharded_mean_log_likelihood(lp, xs)
+        ctx["barrier"]()
+    eel = ctx["max_over_ranks"](time.perf_counter() - t0)
+    return {"value": round(rows / eel, 1), "unit": "samples/s", "rows": rows, "scaling": "strong",
+            "mean_log_likelihood": round(mean_lp, 5),
+            "workload": "log-likelihood of %d synthetic points under the trained gu_num=8 CNF (d=1 checkpoint), "
+                        "tile-local dopri5 1e-5, batch-sharded, one all-reduce of 2 x f64" % rows}
+
+
+def measure_cpu(ctx):
+    """cpu_baseline: the oracle (PyTorch-CPU restatement of the reference path) on the same first batches."""
+    import oracle
+    args, batches = ctx["args"], ctx["batches"]
+    ncores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    torch.manual_seed(1)
+    om = oracle.build_cnf(2).train()
+    oopt = torch.optim.Adam(om.parameters(), lr=1e-3, weight_decay=1e-5)
+    cpu_batches = [b.cpu() for b in batches[: args.cpu_iters + 1]]
+
+    def ostep(x):
+        oopt.zero_grad(set_to_none=True)
+        z, dl = om(x, torch.zeros(x.shape[0], 1))
+        loss = -(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()
+        loss.backward()
+        oopt.step()
+
+    ostep(cpu_batches[0])
+    t0 = time.perf_counter()
+    for x in cpu_batches[1:]:
+        ostep(x)
+    cel = time.perf_counter() - t0
+    return {"value": round(args.cpu_iters / cel, 4), "unit": "iters/s", "cores": ncores, "kind": "port",
+            "sample": "%d training iterations of the same workload (same seed-1 init, same first batches) on the "
+                      "PyTorch-CPU oracle, torch.set_num_threads(%d)" % (args.cpu_iters, ncores)}
 
 
 if __name__ == "__main__":

@@ -86,7 +86,7 @@ class CNF(nn.Module):
                                    "and has no CPU fallback" % z.device)
         _logpz = torch.zeros(z.shape[0], 1).to(z) if logpz is None else logpz
         if integration_times is None:
-            t0, t1 = 0.0, float(self.sqrt_end_time.detach() * self.sqrt_end_time.detach())
+            t0, t1 = 0.0, self._end_time()
         else:
             if len(integration_times) != 2:
                 raise NotImplementedError("the fused integrator returns the state at the end time only")
@@ -106,6 +106,17 @@ class CNF(nn.Module):
         z_t, logpz_t = _Solve.apply(z, _logpz, flat, self, t0, t1, opts, net, e)
         self.regularization_states = ()
         return (z_t, logpz_t) if logpz is not None else z_t
+
+    def _end_time(self):
+        """T = sqrt_end_time**2 as a host float (fp32 product, like the reference's torch.tensor([0, s*s]).to(z)).
+        Read back from the device only when the tensor changed: the value is detached from the graph, so it never
+        trains, and a read-back per solve would be a host sync."""
+        s = self.sqrt_end_time
+        key = (s._version, s.data_ptr())
+        if getattr(self, "_end_time_key", None) != key:
+            self._end_time_val = float(s.detach() * s.detach())
+            self._end_time_key = key
+        return self._end_time_val
 
     def get_regularization_states(self):
         reg_states = self.regularization_states
