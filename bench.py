@@ -228,16 +228,29 @@ def measure_eval(ctx):
     comp = torch.randint(0, 8, (half,), generator=g, device=dev).float() * 10 + 10
     xs = torch.cat([comp + (torch.rand(half, generator=g, device=dev) * 6 - 3),
                     45 + 23 * torch.randn(n_loc - half, generator=g, device=dev)]).reshape(-1, 1)
-    lp = lambda v: parallel_eval.model_log_prob(em, v)  # noqa: E731
+    work = {"row_evals": 0, "nfe_max": 0}
+
+    def lp(v):
+        parts = []
+        for vc in torch.split(v, 1 << 18):       # one launch per 262 144 rows; tile-local control needs no residency
+            parts.append(parallel_eval.model_log_prob(em, vc, chunk=1 << 18))
+            st = em.chain[0].last_stats["forward"]
+            work["row_evals"] += st.row_evals
+            work["nfe_max"] = max(work["nfe_max"], st.nfe)
+        return torch.cat(parts, 0)
+
     with torch.no_grad():
         parallel_eval.sharded_mean_log_likelihood(lp, xs[: 1 << 14])
+        work["row_evals"], work["nfe_max"] = 0, 0
         ctx["barrier"]()
         t0 = time.perf_counter()
         mean_lp, rows = parallel_eval.sharded_mean_log_likelihood(lp, xs)
         ctx["barrier"]()
     eel = ctx["max_over_ranks"](time.perf_counter() - t0)
     return {"value": round(rows / eel, 1), "unit": "samples/s", "rows": rows, "scaling": "strong",
-            "mean_log_likelihood": round(mean_lp, 5),
+            "mean_log_likelihood": round(mean_lp, 5), "rank0_mean_nfe": round(work["row_evals"] / max(1, n_loc), 1),
+            "rank0_max_nfe": work["nfe_max"],
+            "rank0_tflops": round(work["row_evals"] * F_EVAL_D1 / eel / 1e12, 3),
             "workload": "log-likelihood of %d synthetic points under the trained gu_num=8 CNF (d=1 checkpoint), "
                         "tile-local dopri5 1e-5, batch-sharded, one all-reduce of 2 x f64" % rows}
 
