@@ -11,6 +11,11 @@ namespace cnf {
 hipError_t launch_eval_aug(int D, bool hutch, const SolveArgs& a, float t, const float* z, const float* a_z,
                            const float* a_logp, float* f_out, float* nd_out, float* vjp_z_out, hipStream_t s);
 hipError_t launch_solve_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
+// feature-split (one tile per workgroup) variants, cnf_split.hip
+hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
+hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
+hipError_t launch_split_aug(int D, bool hutch, const SolveArgs& a, float t, const float* z, const float* a_z,
+                            const float* a_l, float* f_out, float* nd_out, float* vz_out, hipStream_t s);
 }  // namespace cnf
 
 namespace {
@@ -46,6 +51,14 @@ int check_net(const CnfNetDesc* n) {
 
 long n_wg(long rows) { return (rows + cnf::kRowsPerWG - 1) / cnf::kRowsPerWG; }
 
+// batch-global solves of up to 16*256 rows run one tile per workgroup (cnf_split.hip): every workgroup resident
+bool use_split(const CnfNetDesc* n, long rows) {
+    return n->dim <= 2 && rows <= (long)cnf::kRows * cnf::kMaxWG;
+}
+long n_slabs(const CnfNetDesc* n, long rows) {
+    return use_split(n, rows) ? (rows + cnf::kRows - 1) / cnf::kRows : n_wg(rows);
+}
+
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 }  // namespace
@@ -62,7 +75,7 @@ int64_t cnf_param_count(const CnfNetDesc* net) {
 size_t cnf_workspace_bytes(const CnfNetDesc* net, int64_t rows) {
     if (!supported(net) || rows <= 0) return 0;
     const size_t P = (size_t)cnf::make_layout(net->dim, net->hidden).total;
-    return kGranBytes + align16((size_t)n_wg(rows) * P * sizeof(float));
+    return kGranBytes + align16((size_t)n_slabs(net, rows) * P * sizeof(float));
 }
 
 int cnf_eval_field(const CnfNetDesc* net, const float* params, float t, const float* z, const float* e,
@@ -147,7 +160,10 @@ int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, co
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(workspace, 0, kGranBytes, s);
     if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
-    if (err == hipSuccess) err = cnf::launch_solve_fwd(net->dim, hutch, a, opts->solver, global, s);
+    if (err == hipSuccess) {
+        if (opts->solver == CNF_SOLVER_DOPRI5 && global && use_split(net, rows)) err = cnf::launch_split_fwd(net->dim, hutch, a, s);
+        else err = cnf::launch_solve_fwd(net->dim, hutch, a, opts->solver, global, s);
+    }
     if (err != hipSuccess) return fail("cnf_solve_fwd: launch failed: %s", hipGetErrorString(err));
     return 0;
 }
@@ -173,7 +189,10 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
     a.grad_params = vjp_params_out;
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(workspace, 0, need, s);   // granules + per-workgroup gradient slabs
-    if (err == hipSuccess) err = cnf::launch_eval_aug(net->dim, hutch, a, t, z, a_z, a_logp, f_out, neg_div_out, vjp_z_out, s);
+    if (err == hipSuccess) {
+        if (use_split(net, rows)) err = cnf::launch_split_aug(net->dim, hutch, a, t, z, a_z, a_logp, f_out, neg_div_out, vjp_z_out, s);
+        else err = cnf::launch_eval_aug(net->dim, hutch, a, t, z, a_z, a_logp, f_out, neg_div_out, vjp_z_out, s);
+    }
     if (err != hipSuccess) return fail("cnf_eval_aug: launch failed: %s", hipGetErrorString(err));
     return 0;
 }
@@ -202,7 +221,7 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // granules + gradient slabs
     if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
-    if (err == hipSuccess) err = cnf::launch_solve_bwd(net->dim, hutch, a, s);
+    if (err == hipSuccess) err = use_split(net, rows) ? cnf::launch_split_bwd(net->dim, hutch, a, s) : cnf::launch_solve_bwd(net->dim, hutch, a, s);
     if (err != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(err));
     return 0;
 }

@@ -1,0 +1,1041 @@
+// cnf_split.hip -- latency-oriented variants of the batch-global dopri5 solves: ONE 16-row tile per WORKGROUP.
+//
+// The one-wave-per-tile kernels (cnf_fwd.hip / cnf_bwd.hip) are the throughput design: no barriers, every wave
+// does all 64 output features of every layer.  At the training batch size (2048 rows = 128 tiles) that leaves
+// 7/8 of the chip idle and one evaluation costs ~10 us (forward) / ~33 us (augmented).  Here the four waves of a
+// workgroup split the OUTPUT FEATURES of every layer: wave w computes feature tile w (features 16w..16w+15) for
+// all streams, i.e. a quarter of the MFMAs, of the tanh/gate arithmetic and of the saved state.  A layer's input
+// needs all 64 features, so after each layer every wave publishes its tile to LDS in the C/D register layout
+// (one ds_write_b128 per stream) and reads the four tiles back as B operands (ds_read_b128) behind one
+// workgroup barrier: 3 barriers per forward evaluation, 6 per augmented evaluation.  2048 rows now occupy 128
+// CUs and the dependent chain per evaluation is ~4x shorter.  Every wave keeps its own copy of the 16 rows'
+// Runge-Kutta state (identical arithmetic, bit-identical results), so the controller logic is unchanged.
+// Used when rows <= 16 * 256 (every workgroup resident for the grid-wide reductions); larger batch-global solves
+// fall back to the one-wave-per-tile kernels.
+#include "cnf_launch.h"
+
+namespace cnf {
+
+constexpr int kNSMax = 3;
+
+template <int C>
+struct alignas(16) SplitWaveLds {
+    float gate[3][2][kH];
+    float gate4[2][16];
+    float kst[7][C][kRows];
+};
+
+template <int D>
+struct alignas(16) SplitXchg {
+    float xb[2][kNSMax][4][64][4];   // activations / cotangents in C-D layout: [buffer][stream][feature tile][lane][r]
+    float part[kNW][2 * D][kRows];   // layer-4 partial sums of every wave
+};
+
+template <class WS, int D>
+__device__ __forceinline__ void gates_into(const NetLds<D>& n, WS& ws, int lane, float t) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const float g = sigmoid_f(fmaf(n.vec[l][2][lane], t, n.vec[l][3][lane]));
+        ws.gate[l][0][lane] = g;
+        ws.gate[l][1][lane] = fmaf(g, n.vec[l][0][lane], n.vec[l][1][lane] * t);
+    }
+    if (lane < 16) {
+        const float g = sigmoid_f(fmaf(n.vec4[2][lane], t, n.vec4[3][lane]));
+        ws.gate4[0][lane] = g;
+        ws.gate4[1][lane] = fmaf(g, n.vec4[0][lane], n.vec4[1][lane] * t);
+    }
+    wave_lds_fence();
+}
+
+__device__ __forceinline__ float sum4(float a, float b, float c, float d) { return ((a + b) + c) + d; }
+
+// ---- forward dynamics, feature-split over the 4 waves ---------------------------------------------------
+template <int D, bool HUTCH, class WS>
+__device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, SplitXchg<D>& xc, int lane, int wave, float t,
+                                                const float (&z)[D], const float (&e)[D], float (&f)[D], float& div) {
+    constexpr int NT = HUTCH ? 1 : D;
+    constexpr int NS = NT + 1;
+    const int q = lane >> 4, j = lane & 15;
+    const int fo = 16 * wave + 4 * q;
+    gates_into(n, ws, lane, t);
+    f32x4 act[NS];
+    {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[0][0][fo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[0][1][fo]);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
+        f32x4 wcol[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            wcol[m] = *reinterpret_cast<const f32x4*>(&n.w1[m][fo]);
+            a += wcol[m] * z[m];
+            if (HUTCH) au += wcol[m] * e[m];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
+            const float dg = (1.0f - x * x) * g[r];
+            act[0][r] = x;
+            if (HUTCH) {
+                act[1][r] = dg * au[r];
+            } else {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) act[1 + m][r] = dg * wcol[m][r];
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
+        __syncthreads();
+        f32x4 acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&n.wimg[l][wave * 4 + Ti][lane][0]);
+            f32x4 in[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s] = mfma16(a[r], in[s][r], acc[s]);
+        }
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = tanh_f(fmaf(g[r], acc[0][r], c[r]));
+            const float dg = (1.0f - x * x) * g[r];
+            act[0][r] = x;
+#pragma unroll
+            for (int s = 1; s < NS; ++s) act[s][r] = dg * acc[s][r];
+        }
+    }
+    // layer 4: this wave's 16 features, then across waves through LDS
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&n.w4[m][fo]);
+        float pf = 0.f, pd = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf = fmaf(w4[r], act[0][r], pf);
+            pd = fmaf(w4[r], act[HUTCH ? 1 : 1 + m][r], pd);
+        }
+        pf = xq_sum(pf);
+        pd = xq_sum(pd);
+        if (q == 0) {
+            xc.part[wave][m][j] = pf;
+            xc.part[wave][D + m][j] = pd;
+        }
+    }
+    __syncthreads();
+    div = 0.f;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        const float g4 = ws.gate4[0][m];
+        const float u4 = sum4(xc.part[0][m][j], xc.part[1][m][j], xc.part[2][m][j], xc.part[3][m][j]);
+        const float U4 = sum4(xc.part[0][D + m][j], xc.part[1][D + m][j], xc.part[2][D + m][j], xc.part[3][D + m][j]);
+        f[m] = fmaf(g4, u4, ws.gate4[1][m]);
+        const float dm = g4 * U4;
+        div += HUTCH ? dm * e[m] : dm;
+    }
+}
+
+// ---- forward solve -----------------------------------------------------------------------------------------
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
+    constexpr int C = D + 1;
+    __shared__ NetLds<D> net;
+    __shared__ SplitWaveLds<C> wl[kNW];
+    __shared__ SplitXchg<D> xc;
+    __shared__ RedLds red;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    if (tid == 0) red.status = 0;
+    stage_net(net, a.params, tid);
+    __syncthreads();
+    const long row = (long)blockIdx.x * kRows + j;
+    const bool counted = row < a.rows && lane < 16 && w == 0;   // every wave carries the same 16 rows: count them once
+    const long rr = row < a.rows ? row : a.rows - 1;
+    SplitWaveLds<C>& ws = wl[w];
+
+    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    const double nl = (double)a.rows, nz = nl * D;
+
+    float y0[C], y1[C], yi[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y0[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+    }
+    y0[D] = a.logp0 ? a.logp0[rr] : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) yi[c] = y0[c];
+
+    const float sgn = a.t1 >= a.t0 ? 1.f : -1.f;
+    const double tau_end = (double)(sgn * a.t1);
+    double tau = (double)(sgn * a.t0);
+    double dt = 0.0;
+    float dtf = 0.f, t0f = (float)tau, ti = t0f;
+    const float rtol = a.rtol, atol = a.atol;
+
+    enum { PH_F0 = 0, PH_F1 = 1, PH_STAGE = 2 };
+    int phase = PH_F0, stage = 0;
+    int nfe = 0, nacc = 0, nrej = 0, status = 0;
+    float h0 = 0.f, d1z = 0.f, d1l = 0.f;
+    float sc[C];
+
+    for (;;) {
+        float zz[D], f[D], div, k[C];
+        bool restart = false;
+#pragma unroll
+        for (int m = 0; m < D; ++m) zz[m] = yi[m];
+        field_fwd_split<D, HUTCH>(net, ws, xc, lane, w, sgn * ti, zz, ee, f, div);
+        ++nfe;
+#pragma unroll
+        for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
+        k[D] = -sgn * div;
+
+        if (phase == PH_F0) {
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                ws.kst[0][c][j] = k[c];
+                sc[c] = atol + fabsf(y0[c]) * rtol;
+                const float u = y0[c] / sc[c], v = k[c] / sc[c];
+                if (counted) {
+                    S[c < D ? 0 : 1] += (double)u * u;
+                    S[c < D ? 2 : 3] += (double)v * v;
+                }
+            }
+            if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
+            d1z = (float)sqrt(S[2] / nz);
+            d1l = (float)sqrt(S[3] / nl);
+            if (pymax(d0z, d0l) < 1e-5f || pymax(d1z, d1l) < 1e-5f) {
+                h0 = 1e-6f;
+            } else {
+                h0 = 0.01f * pymax(d0z / d1z, d0l / d1l);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) yi[c] = y0[c] + h0 * k[c];
+            ti = t0f + h0;
+            phase = PH_F1;
+            continue;
+        }
+        if (phase == PH_F1) {
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float u = (k[c] - ws.kst[0][c][j]) / sc[c];
+                if (counted) S[c < D ? 0 : 1] += (double)u * u;
+            }
+            if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
+            float h1;
+            if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
+                h1 = fmaxf(1e-6f, h0 * 1e-3f);
+            } else {
+                h1 = powf(0.01f / pymax(pymax(pymax(d1z, d1l), d2z), d2l), 0.2f);
+            }
+            dt = (double)fminf(100.f * h0, h1);
+            restart = true;
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) ws.kst[stage][c][j] = k[c];
+            if (stage < 6) {
+                ++stage;
+            } else {
+                double S[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    y1[c] = yi[c];
+                    float err = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c]));
+                    const float u = err / tol;
+                    if (counted) {
+                        S[c < D ? 0 : 1] += (double)u * u;
+                        if (!isfinite(y0[c])) S[2] += 1.0;
+                    }
+                }
+                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
+                const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
+                const bool accept = (rz <= 1.f) && (rl <= 1.f);
+                if (accept) {
+                    ++nacc;
+                    if (!(tau_end > tau + dt)) break;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        y0[c] = y1[c];
+                        ws.kst[0][c][j] = k[c];
+                    }
+                    tau = tau + dt;
+                } else {
+                    ++nrej;
+                }
+                dt = next_step_size(dt, pymax(rz, rl));
+                restart = true;
+            }
+        }
+        if (restart) {
+            if (!(tau + dt > tau)) { status = CNF_ERR_DT_UNDERFLOW; break; }
+            if (nacc + nrej >= a.max_steps) { status = CNF_ERR_MAX_STEPS; break; }
+            dtf = (float)dt;
+            t0f = (float)tau;
+            stage = 1;
+            phase = PH_STAGE;
+        }
+        ti = t0f + kAlpha[stage - 1] * dtf;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+            for (int s = 0; s < stage; ++s) acc += (dtf * kBeta[stage - 1][s]) * ws.kst[s][c][j];
+            yi[c] = y0[c] + acc;
+        }
+    }
+
+    if (status == 0) {
+        const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+        const float x = (te - ta) / (tb - ta);
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float mid = 0.f;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * ws.kst[s][c][j];
+            mid = y0[c] + mid;
+            const float f0 = ws.kst[0][c][j], f1 = ws.kst[6][c][j], u = y0[c], v = y1[c];
+            const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
+            const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
+            const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
+            const float cd = dtf * f0;
+            y1[c] = ca * x4 + cb * x3 + cc * x2 + cd * x + u;
+        }
+        if (counted) {
+#pragma unroll
+            for (int m = 0; m < D; ++m) a.z_out[row * D + m] = y1[m];
+            a.logp_out[row] = y1[D];
+        }
+    }
+    if (tid == 0 && (blockIdx.x == 0 || status != 0)) {
+        if (status) atomicMax(&a.stats->status, status);
+        atomicMax(&a.stats->nfe, nfe);
+        atomicMax(&a.stats->n_accepted, nacc);
+        atomicMax(&a.stats->n_rejected, nrej);
+        atomicMax(&a.stats->evals_run, nfe);
+        a.stats->last_dt = (float)dt;
+        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(a.rows * (long)nfe));
+    }
+}
+
+// ============================================================================================================
+// adjoint, feature-split
+// ============================================================================================================
+template <int D>
+struct SmallIdxS {   // parameters other than the two 64x64 matrices, canonical order with those matrices cut out
+    static constexpr int n0 = kH * D + 4 * kH;
+    static constexpr int v2 = n0;
+    static constexpr int v3 = n0 + 4 * kH;
+    static constexpr int l4 = n0 + 8 * kH;
+    static constexpr int count = l4 + kH * D + 4 * D;
+    static constexpr int padded = (count + 3) & ~3;
+    __host__ __device__ static int vec(int layer) { return layer == 0 ? kH * D : (layer == 1 ? v2 : v3); }
+    __host__ __device__ static int canonical(int si) { return si < n0 ? si : (si < v3 ? si + kH * kH : si + 2 * kH * kH); }
+};
+
+template <int D>
+struct alignas(16) SplitBwdLds {
+    float wimgT[2][16][64][4];            // as BwdNetLds::wimgT
+    float trB[2][kNSMax][kH * kRows];     // transposed layer inputs, all 64 features: [buffer][stream][feature*16 + pos(row)]
+    float trA[kNW][kNSMax][16 * kRows];   // per wave: transposed, weighted cotangents of its own 16 features
+    float small[SmallIdxS<D>::padded];    // the step's d/dtheta of the small parameters (waves own disjoint features)
+    float part2[kNW][D][kRows];           // vjp_z partial sums of every wave
+    float wq[8];                          // quadrature weights of the current attempt
+};
+
+__device__ __forceinline__ float row16_allsum_s(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+struct BigAccS {
+    f32x4 gw[2][4];   // [layer][Tin]: lane (q, j') reg r = dW[16*wave+4q+r][16Tin+j']
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) gw[l][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// one augmented evaluation; same mathematics as aug_eval (cnf_bwd.hip), each wave on its own feature tile
+template <int D, bool HUTCH, class WS>
+__device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D>& sb, WS& ws, SplitXchg<D>& xc, int lane,
+                                               int wave, float t, const float (&z)[D], const float (&e)[D],
+                                               const float (&az)[D], float al, float w, bool with_theta, float (&f)[D],
+                                               float& div, float (&vz)[D], BigAccS& acc) {
+    constexpr int NT = HUTCH ? 1 : D;
+    constexpr int NS = NT + 1;
+    using SI = SmallIdxS<D>;
+    const int q = lane >> 4, j = lane & 15, qq = j & 3;
+    const int fo = 16 * wave + 4 * q;
+    const int pos = (j & 3) * 4 + (j >> 2);
+    gates_into(n, ws, lane, t);
+
+    // ------------------------------------------------------------------ forward with saves (own tile)
+    f32x4 xs[3], ub[3], U[2][NT], act[NS];
+    f32x4 w1c[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) w1c[m] = *reinterpret_cast<const f32x4*>(&n.w1[m][fo]);
+    {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[0][0][fo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[0][1][fo]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[0][0][fo]);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            a += w1c[m] * z[m];
+            if (HUTCH) au += w1c[m] * e[m];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
+            const float dg = (1.0f - x * x) * g[r];
+            xs[0][r] = x;
+            ub[0][r] = a[r] + b[r];
+            act[0][r] = x;
+            if (HUTCH) {
+                act[1][r] = dg * au[r];
+            } else {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) act[1 + m][r] = dg * w1c[m][r];
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
+        __syncthreads();
+        f32x4 a4[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a4[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&n.wimg[l][wave * 4 + Ti][lane][0]);
+            f32x4 in[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a4[s] = mfma16(a[r], in[s][r], a4[s]);
+        }
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[l + 1][0][fo]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = tanh_f(fmaf(g[r], a4[0][r], c[r]));
+            const float dg = (1.0f - x * x) * g[r];
+            xs[l + 1][r] = x;
+            ub[l + 1][r] = a4[0][r] + b[r];
+            act[0][r] = x;
+#pragma unroll
+            for (int s = 1; s < NS; ++s) {
+                U[l][s - 1][r] = a4[s][r];
+                act[s][r] = dg * a4[s][r];
+            }
+        }
+    }
+    f32x4 w4[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        w4[m] = *reinterpret_cast<const f32x4*>(&n.w4[m][fo]);
+        float pf = 0.f, pd = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf = fmaf(w4[m][r], act[0][r], pf);
+            pd = fmaf(w4[m][r], act[HUTCH ? 1 : 1 + m][r], pd);
+        }
+        pf = xq_sum(pf);
+        pd = xq_sum(pd);
+        if (q == 0) {
+            xc.part[wave][m][j] = pf;
+            xc.part[wave][D + m][j] = pd;
+        }
+    }
+    __syncthreads();
+    float g4[D], u4[D], U4[D];
+    div = 0.f;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        g4[m] = ws.gate4[0][m];
+        u4[m] = sum4(xc.part[0][m][j], xc.part[1][m][j], xc.part[2][m][j], xc.part[3][m][j]);
+        U4[m] = sum4(xc.part[0][D + m][j], xc.part[1][D + m][j], xc.part[2][D + m][j], xc.part[3][D + m][j]);
+        f[m] = fmaf(g4[m], u4[m], ws.gate4[1][m]);
+        const float dm = g4[m] * U4[m];
+        div += HUTCH ? dm * e[m] : dm;
+    }
+
+    // ------------------------------------------------------------------ reverse sweep (own tile)
+    float lf[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) lf[m] = -az[m];
+    const float ld = al;
+    f32x4 cot[NS];
+    {
+        float ubar[D], Ubar[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            ubar[m] = g4[m] * lf[m];
+            Ubar[m] = g4[m] * ld * (HUTCH ? e[m] : 1.0f);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float xb = 0.f, Xh = 0.f;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                xb = fmaf(ubar[m], w4[m][r], xb);
+                if (HUTCH) Xh = fmaf(Ubar[m], w4[m][r], Xh);
+                else cot[1 + (HUTCH ? 0 : m)][r] = Ubar[m] * w4[m][r];
+            }
+            cot[0][r] = xb;
+            if (HUTCH) cot[1][r] = Xh;
+            if (with_theta) {
+                float mine = 0.f;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    const float v = row16_allsum_s(ubar[m] * act[0][r] + Ubar[m] * act[HUTCH ? 1 : 1 + m][r]);
+                    mine = (j == m) ? v : mine;
+                }
+                if (j < D) sb.small[SI::l4 + j * kH + fo + r] += w * mine;
+            }
+        }
+        if (with_theta) {
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                const float s4 = row16_allsum_s(lf[m]);
+                const float gb = row16_allsum_s(lf[m] * (u4[m] + n.vec4[0][m]) + ld * (HUTCH ? e[m] : 1.0f) * U4[m]);
+                const float gg = g4[m] * (1.0f - g4[m]);
+                const float val = qq < 2 ? s4 : gb;
+                const float fac = qq == 0 ? g4[m] : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
+                if (wave == 0 && lane < 4) sb.small[SI::l4 + kH * D + qq * D + m] += w * fac * val;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int l = 1; l >= -1; --l) {
+        const int L = l + 1;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[L][0][fo]);
+        float s1[4], s2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = xs[L][r];
+            const float dx = 1.0f - x * x;
+            float pre = dx * cot[0][r];
+            float q2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                float Uk;
+                if (l >= 0) {
+                    Uk = U[l < 0 ? 0 : l][k][r];
+                } else if (HUTCH) {
+                    Uk = 0.f;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) Uk = fmaf(w1c[m][r], e[m], Uk);
+                } else {
+                    Uk = w1c[k][r];
+                }
+                const float Xb = cot[1 + k][r];
+                pre = fmaf(Xb * (g[r] * Uk), -2.0f * x * dx, pre);
+                const float Pb = dx * Xb;
+                q2 = fmaf(Pb, Uk, q2);
+                cot[1 + k][r] = g[r] * Pb;
+            }
+            s1[r] = pre;
+            s2[r] = fmaf(pre, ub[L][r], q2);
+            cot[0][r] = g[r] * pre;
+        }
+        if (with_theta) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float st = row16_allsum_s(s1[r]);
+                const float gt = row16_allsum_s(s2[r]);
+                const float gg = g[r] * (1.0f - g[r]);
+                const float val = qq < 2 ? st : gt;
+                const float fac = qq == 0 ? g[r] : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
+                if (j < 4) sb.small[SI::vec(L) + qq * kH + fo + r] += w * fac * val;
+            }
+        }
+        if (l >= 0) {
+            const int lc = l < 0 ? 0 : l;
+            const int buf = 1 - lc;   // layer 3 publishes through buffer 0, layer 2 through buffer 1
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
+            if (with_theta) {
+                const f32x4 gi = *reinterpret_cast<const f32x4*>(&ws.gate[L - 1][0][fo]);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float xin;
+                        if (s == 0) {
+                            xin = xs[L - 1][r];
+                        } else {
+                            const float xi = xs[L - 1][r];
+                            float Uin;
+                            if (lc > 0) {
+                                Uin = U[lc > 0 ? lc - 1 : 0][s - 1][r];
+                            } else if (HUTCH) {
+                                Uin = 0.f;
+#pragma unroll
+                                for (int m = 0; m < D; ++m) Uin = fmaf(w1c[m][r], e[m], Uin);
+                            } else {
+                                Uin = w1c[s - 1][r];
+                            }
+                            xin = (1.0f - xi * xi) * gi[r] * Uin;
+                        }
+                        sb.trA[wave][s][(4 * q + r) * kRows + pos] = w * cot[s][r];
+                        sb.trB[buf][s][(fo + r) * kRows + pos] = xin;
+                    }
+                }
+            }
+            __syncthreads();
+            if (with_theta) {
+                // dW[16*wave + i'][:] += sum_rows (w ubar)[i'][row] * x_in[:][row]   (K = the 16 rows)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.trA[wave][s][j * kRows + 4 * q]);
+                    f32x4 b4[4];
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) b4[T] = *reinterpret_cast<const f32x4*>(&sb.trB[buf][s][(16 * T + j) * kRows + 4 * q]);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int Ti = 0; Ti < 4; ++Ti) acc.gw[lc][Ti] = mfma16(a4[ks], b4[Ti][ks], acc.gw[lc][Ti]);
+                }
+            }
+            // cotangent of this layer's input, own input-feature tile: (W^T ubar)[16*wave ..]
+            f32x4 o4[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) o4[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int To = 0; To < 4; ++To) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&sb.wimgT[lc][wave * 4 + To][lane][0]);
+                f32x4 in[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[buf][s][To][lane][0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) o4[s] = mfma16(a[r], in[s][r], o4[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) cot[s] = o4[s];
+        } else {
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                float pz = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pz = fmaf(w1c[m][r], cot[0][r], pz);
+                pz = xq_sum(pz);
+                if (q == 0) sb.part2[wave][m][j] = pz;
+            }
+            if (with_theta) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float mine = 0.f;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) {
+                        const float tang = HUTCH ? cot[1][r] * e[m] : cot[1 + (HUTCH ? 0 : m)][r];
+                        const float v = row16_allsum_s(fmaf(cot[0][r], z[m], tang));
+                        mine = (j == m) ? v : mine;
+                    }
+                    if (j < D) sb.small[(fo + r) * D + j] += w * mine;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < D; ++m)
+                vz[m] = sum4(sb.part2[0][m][j], sb.part2[1][m][j], sb.part2[2][m][j], sb.part2[3][m][j]);
+        }
+    }
+}
+
+template <int D>
+__device__ inline void commit_step_split(SplitBwdLds<D>& sb, const BigAccS& acc, float* __restrict__ slab_wg, int tid) {
+    const ParamLayout L = make_layout(D, kH);
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    __syncthreads();
+    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads) slab_wg[SmallIdxS<D>::canonical(i)] += sb.small[i];
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] += acc.gw[l][Ti][r];
+    __syncthreads();
+}
+
+template <int D>
+__device__ inline void stage_wimgT(float* img, const float* __restrict__ p, int tid) {
+    const ParamLayout L = make_layout(D, kH);
+    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += kThreads) {
+        const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
+        const int row = 16 * (tt & 3) + 4 * (lane >> 4) + r;
+        const int col = 16 * (tt >> 2) + (lane & 15);
+        img[idx] = p[L.w(1 + l) + row * kH + col];
+    }
+}
+
+// single augmented evaluation (cnf_eval_aug, rows <= 4096)
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float t, const float* __restrict__ z,
+                                                             const float* __restrict__ a_z, const float* __restrict__ a_l,
+                                                             float* __restrict__ f_out, float* __restrict__ nd_out,
+                                                             float* __restrict__ vz_out) {
+    constexpr int C = 2 * D + 1;
+    __shared__ NetLds<D> net;
+    __shared__ SplitBwdLds<D> sb;
+    __shared__ SplitWaveLds<C> wl[kNW];
+    __shared__ SplitXchg<D> xc;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    stage_net(net, a.params, tid);
+    stage_wimgT<D>(&sb.wimgT[0][0][0][0], a.params, tid);
+    for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) sb.small[i] = 0.f;
+    __syncthreads();
+    const long row = (long)blockIdx.x * kRows + j;
+    const bool valid = row < a.rows;
+    const long rr = valid ? row : a.rows - 1;
+    float zz[D], ee[D], az[D], f[D], vz[D], div;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        zz[m] = z[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+        az[m] = valid ? a_z[rr * D + m] : 0.f;
+    }
+    const float al = valid ? a_l[rr] : 0.f;
+    BigAccS acc;
+    acc.zero();
+    aug_eval_split<D, HUTCH>(net, sb, wl[w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc);
+    if (w == 0 && lane < 16 && valid) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            f_out[row * D + m] = f[m];
+            vz_out[row * D + m] = vz[m];
+        }
+        nd_out[row] = -div;
+    }
+    commit_step_split<D>(sb, acc, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, tid);
+}
+
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a) {
+    constexpr int C = 2 * D + 1;
+    constexpr int CE = D + 1;
+    __shared__ NetLds<D> net;
+    __shared__ SplitBwdLds<D> sb;
+    __shared__ SplitWaveLds<C> wl[kNW];
+    __shared__ SplitXchg<D> xc;
+    __shared__ RedLds red;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    if (tid == 0) red.status = 0;
+    stage_net(net, a.params, tid);
+    stage_wimgT<D>(&sb.wimgT[0][0][0][0], a.params, tid);
+    __syncthreads();
+    const long row = (long)blockIdx.x * kRows + j;
+    const bool valid = row < a.rows;
+    const bool counted = valid && lane < 16 && w == 0;
+    const long rr = valid ? row : a.rows - 1;
+    SplitWaveLds<C>& ws = wl[w];
+    float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;
+
+    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    const double nl = (double)a.rows, nz = nl * D;
+
+    float y0[C], y1[C], yi[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y0[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+        y0[D + 1 + m] = valid ? a.grad_z1[rr * D + m] : 0.f;
+    }
+    y0[D] = a.logp0[rr];
+    const float al = valid ? a.grad_logp1[rr] : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) yi[c] = y0[c];
+
+    const float sgn = a.t0 >= a.t1 ? 1.f : -1.f;
+    const double tau_end = (double)(sgn * a.t0);
+    double tau = (double)(sgn * a.t1);
+    double dt = 0.0;
+    float dtf = 0.f, t0f = (float)tau, ti = t0f;
+    const float rtol = a.rtol, atol = a.atol;
+
+    enum { PH_F0 = 0, PH_F1 = 1, PH_STAGE = 2 };
+    int phase = PH_F0, stage = 0;
+    int nacc = 0, nrej = 0, status = 0, nrun = 0;
+    float h0 = 0.f, d1z = 0.f, d1l = 0.f;
+    float sc[CE];
+    BigAccS acc;
+    acc.zero();
+
+    for (;;) {
+        float zz[D], az[D], f[D], vz[D], div, k[C];
+        bool restart = false;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            zz[m] = yi[m];
+            az[m] = yi[D + 1 + m];
+        }
+        const float wst = phase == PH_STAGE ? sb.wq[stage] : 0.f;
+        const bool with_theta = wst != 0.f;
+        aug_eval_split<D, HUTCH>(net, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc);
+        ++nrun;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            k[m] = sgn * f[m];
+            k[D + 1 + m] = sgn * vz[m];
+        }
+        k[D] = -sgn * div;
+
+        if (phase == PH_F0) {
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < CE; ++c) {
+                ws.kst[0][c][j] = k[c];
+                sc[c] = atol + fabsf(y0[c]) * rtol;
+                const float u = y0[c] / sc[c], v = k[c] / sc[c];
+                if (counted) {
+                    S[c < D ? 0 : 1] += (double)u * u;
+                    S[c < D ? 2 : 3] += (double)v * v;
+                }
+            }
+#pragma unroll
+            for (int c = CE; c < C; ++c) ws.kst[0][c][j] = k[c];
+            if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
+            d1z = (float)sqrt(S[2] / nz);
+            d1l = (float)sqrt(S[3] / nl);
+            if (pymax(d0z, d0l) < 1e-5f || pymax(d1z, d1l) < 1e-5f) {
+                h0 = 1e-6f;
+            } else {
+                h0 = 0.01f * pymax(d0z / d1z, d0l / d1l);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) yi[c] = y0[c] + h0 * k[c];
+            ti = t0f + h0;
+            phase = PH_F1;
+            continue;
+        }
+        if (phase == PH_F1) {
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < CE; ++c) {
+                const float u = (k[c] - ws.kst[0][c][j]) / sc[c];
+                if (counted) S[c < D ? 0 : 1] += (double)u * u;
+            }
+            if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
+            float h1;
+            if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
+                h1 = fmaxf(1e-6f, h0 * 1e-3f);
+            } else {
+                h1 = powf(0.01f / pymax(pymax(pymax(d1z, d1l), d2z), d2l), 0.2f);
+            }
+            dt = (double)fminf(100.f * h0, h1);
+            restart = true;
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) ws.kst[stage][c][j] = k[c];
+            if (stage < 6) {
+                ++stage;
+            } else {
+                double S[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < C; ++c) y1[c] = yi[c];
+#pragma unroll
+                for (int c = 0; c < CE; ++c) {
+                    float err = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c]));
+                    const float u = err / tol;
+                    if (counted) {
+                        S[c < D ? 0 : 1] += (double)u * u;
+                        if (!isfinite(y0[c])) S[2] += 1.0;
+                    }
+                }
+                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
+                const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
+                const bool accept = (rz <= 1.f) && (rl <= 1.f);
+                if (accept) {
+                    ++nacc;
+                    commit_step_split<D>(sb, acc, slab, tid);
+                    if (!(tau_end > tau + dt)) break;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) y0[c] = y1[c];
+                    tau = tau + dt;
+                } else {
+                    ++nrej;
+                }
+                dt = next_step_size(dt, pymax(rz, rl));
+                restart = true;
+            }
+        }
+        if (restart) {
+            if (!(tau + dt > tau)) { status = CNF_ERR_DT_UNDERFLOW; break; }
+            if (nacc + nrej >= a.max_steps) { status = CNF_ERR_MAX_STEPS; break; }
+            dtf = (float)dt;
+            t0f = (float)tau;
+            stage = 0;
+            phase = PH_STAGE;
+            acc.zero();
+            __syncthreads();   // every wave is past its last read of small / wq of the previous attempt
+            for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) sb.small[i] = 0.f;
+            if (tid < 7) {
+                const int s = tid;
+                float v;
+                if (tau_end > tau + dt) {
+                    v = s < 6 ? dtf * kBeta[5][s] : 0.f;
+                } else {
+                    const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+                    const float x = (te - ta) / (tb - ta);
+                    const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+                    const float b = s < 6 ? kBeta[5][s] : 0.f;
+                    const float cm = kCMid[s];
+                    v = dtf * (x4 * (-8.f * b + 16.f * cm) + x3 * (14.f * b - 32.f * cm) + x2 * (-5.f * b + 16.f * cm));
+                    if (s == 0) v += dtf * (-2.f * x4 + 5.f * x3 - 4.f * x2 + x);
+                    if (s == 6) v += dtf * (2.f * x4 - 3.f * x3 + x2);
+                }
+                sb.wq[s] = v;
+            }
+            __syncthreads();
+        }
+        if (stage == 0) {
+            ti = t0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) yi[c] = y0[c];
+        } else {
+            ti = t0f + kAlpha[stage - 1] * dtf;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float s_ = 0.f;
+                for (int s = 0; s < stage; ++s) s_ += (dtf * kBeta[stage - 1][s]) * ws.kst[s][c][j];
+                yi[c] = y0[c] + s_;
+            }
+        }
+    }
+
+    if (status == 0) {
+        const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+        const float x = (te - ta) / (tb - ta);
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const int c = D + 1 + m;
+            float mid = 0.f;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * ws.kst[s][c][j];
+            mid = y0[c] + mid;
+            const float f0 = ws.kst[0][c][j], f1 = ws.kst[6][c][j], u = y0[c], v = y1[c];
+            const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
+            const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
+            const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
+            const float cd = dtf * f0;
+            const float out = ca * x4 + cb * x3 + cc * x2 + cd * x + u;
+            if (counted) a.grad_x[row * D + m] = out;
+        }
+        if (counted) a.grad_logp0[row] = al;
+    }
+    if (tid == 0 && (blockIdx.x == 0 || status != 0)) {
+        if (status) atomicMax(&a.stats->status, status);
+        atomicMax(&a.stats->nfe, 2 + 6 * (nacc + nrej));
+        atomicMax(&a.stats->n_accepted, nacc);
+        atomicMax(&a.stats->n_rejected, nrej);
+        atomicMax(&a.stats->evals_run, nrun);
+        a.stats->last_dt = (float)dt;
+        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(a.rows * (long)nrun));
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------
+__global__ void reduce_slab_split_kernel(const float* __restrict__ slab, int nwg, int P, float* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four fixed partial chains: deterministic, 4 loads in flight
+    int g = 0;
+    for (; g + 3 < nwg; g += 4) {
+        s0 += slab[(size_t)g * P + p];
+        s1 += slab[(size_t)(g + 1) * P + p];
+        s2 += slab[(size_t)(g + 2) * P + p];
+        s3 += slab[(size_t)(g + 3) * P + p];
+    }
+    for (; g < nwg; ++g) s0 += slab[(size_t)g * P + p];
+    out[p] = (s0 + s1) + (s2 + s3);
+}
+
+template <int D, bool HUTCH>
+static hipError_t split_fwd_t(const SolveArgs& a, hipStream_t s) {
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    hipLaunchKernelGGL((dopri5_split_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s) {
+    if (D == 1 && !hutch) return split_fwd_t<1, false>(a, s);
+    if (D == 2 && !hutch) return split_fwd_t<2, false>(a, s);
+    if (D == 2 && hutch) return split_fwd_t<2, true>(a, s);
+    return hipErrorNotSupported;
+}
+
+template <int D, bool HUTCH>
+static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    const int P = make_layout(D, kH).total;
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 127) / 128), dim3(128), 0, s, a.slab, grid, P, a.grad_params);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s) {
+    if (D == 1 && !hutch) return split_bwd_t<1, false>(a, s);
+    if (D == 2 && !hutch) return split_bwd_t<2, false>(a, s);
+    if (D == 2 && hutch) return split_bwd_t<2, true>(a, s);
+    return hipErrorNotSupported;
+}
+
+template <int D, bool HUTCH>
+static hipError_t split_aug_t(const SolveArgs& a, float t, const float* z, const float* a_z, const float* a_l, float* f_out,
+                              float* nd_out, float* vz_out, hipStream_t s) {
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    hipLaunchKernelGGL((aug_split_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a, t, z, a_z, a_l, f_out, nd_out, vz_out);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    const int P = make_layout(D, kH).total;
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 127) / 128), dim3(128), 0, s, a.slab, grid, P, a.grad_params);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_aug(int D, bool hutch, const SolveArgs& a, float t, const float* z, const float* a_z,
+                            const float* a_l, float* f_out, float* nd_out, float* vz_out, hipStream_t s) {
+    if (D == 1 && !hutch) return split_aug_t<1, false>(a, t, z, a_z, a_l, f_out, nd_out, vz_out, s);
+    if (D == 2 && !hutch) return split_aug_t<2, false>(a, t, z, a_z, a_l, f_out, nd_out, vz_out, s);
+    if (D == 2 && hutch) return split_aug_t<2, true>(a, t, z, a_z, a_l, f_out, nd_out, vz_out, s);
+    return hipErrorNotSupported;
+}
+
+}  // namespace cnf

@@ -45,7 +45,8 @@ def _oracle_aug(m, t, z, a_z, a_l, e=None):
     return f.detach(), nd.detach(), vz, vp
 
 
-@pytest.mark.parametrize("case", ["fixture_uni", "fixture_multi", "rand_d1", "rand_d2", "rand_d2_ragged", "rand_d2_hutch"])
+@pytest.mark.parametrize("case", ["fixture_uni", "fixture_multi", "rand_d1", "rand_d2", "rand_d2_ragged", "rand_d2_hutch",
+                                  "rand_d2_big"])
 def test_eval_aug_matches_autograd(case):
     nat = _native()
     g = torch.Generator().manual_seed(17)
@@ -57,7 +58,7 @@ def test_eval_aug_matches_autograd(case):
         z = torch.rand(rows, 1, generator=g) * (1.0 if which == "unimodal" else 76.0) + (4.5 if which == "unimodal" else 7.0)
     else:
         dim = 1 if "d1" in case else 2
-        rows = 77 if "ragged" in case else 256
+        rows = 77 if "ragged" in case else (4500 if "big" in case else 256)   # > 4096 rows: one-wave-per-tile kernels
         m = oracle_random_model(dim, seed=5, divergence_fn="approximate" if hutch else "brute_force", scale=2.0)
         z = torch.randn(rows, dim, generator=g) * 1.5
     m.train()
@@ -98,7 +99,8 @@ def _oracle_train_grads(m, x):
     return loss.item(), z.detach(), dl.detach(), xx.grad.clone(), gp, blk.stats
 
 
-@pytest.mark.parametrize("case,rows", [("rand_d2", 2048), ("rand_d2", 100), ("rand_d1", 64), ("fixture_uni", 512), ("rand_d2_hutch", 256)])
+@pytest.mark.parametrize("case,rows", [("rand_d2", 2048), ("rand_d2", 100), ("rand_d1", 64), ("fixture_uni", 512), ("rand_d2_hutch", 256),
+                                       ("rand_d2", 4200), ("fixture_uni", 4100)])
 def test_solve_bwd_matches_oracle_adjoint(case, rows):
     nat = _native()
     g = torch.Generator().manual_seed(23)

