@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--eval-rows", type=int, default=1 << 20, help="rows of the sharded log-likelihood evaluation")
     p.add_argument("--late-steps", type=int, default=3)
     p.add_argument("--cpu-iters", type=int, default=12, help="oracle iterations timed for cpu_baseline (rank 0, N=1)")
+    p.add_argument("--graph", type=int, default=1, help="1: replay the training iteration as one captured hipGraph; 0: eager")
     p.add_argument("--extras", type=str, default="roofline,late,eval,cpu",
                    help="comma list of the additional measurements to run: roofline, late, eval, cpu ('' = none)")
     return p.parse_args()
@@ -116,18 +117,34 @@ def main():
     batches = [data.get_sample(args.batch).to(dev) for _ in range(args.warmup + args.steps)]
     torch.manual_seed(1 + rank)
     model = gu_ffjord.build_model(2).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
-    for x in batches[:args.warmup]:
-        train_step(model, opt, x, gu_ffjord)
-    nfe_f = nfe_b = 0
-    barrier()
-    t0 = time.perf_counter()
-    for x in batches[args.warmup:]:
-        _, sf, sb = train_step(model, opt, x, gu_ffjord)
-        nfe_f += sf.nfe
-        nfe_b += sb.nfe
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    graphed = None
+    if args.graph:
+        # the whole iteration as one hipGraph replay (gu_ffjord.GraphedTrainStep); warm-up iterations run eagerly
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
+        graphed = gu_ffjord.GraphedTrainStep(model, opt, batches[0], batches[:max(1, args.warmup)])
+        barrier()
+        t0 = time.perf_counter()
+        for x in batches[args.warmup:]:
+            graphed(x)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        graphed.check()
+        nfe_f, nfe_b = [int(v) for v in graphed.nfe.tolist()]
+        for blk in model.chain:
+            blk.sync_stats = True
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        for x in batches[:args.warmup]:
+            train_step(model, opt, x, gu_ffjord)
+        nfe_f = nfe_b = 0
+        barrier()
+        t0 = time.perf_counter()
+        for x in batches[args.warmup:]:
+            _, sf, sb = train_step(model, opt, x, gu_ffjord)
+            nfe_f += sf.nfe
+            nfe_b += sb.nfe
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
     value = world * args.steps / elapsed
     out = {
         "metric": "CNF train iters/s (B=2048, d=2)", "value": round(value, 3), "unit": "iters/s", "n_gpus": world,
@@ -137,6 +154,7 @@ def main():
                                "rtol=atol=1e-5, T=0.5, exact divergence, adjoint backward, Adam; weights from seed-1 "
                                "init (first %d iterations of training)" % (args.batch, args.warmup + args.steps),
                    "global_batch": args.batch * world, "parallelism": "independent trial per GPU (replicas only)",
+                   "launch": "hipGraph replay of the whole iteration" if graphed is not None else "eager",
                    "mean_nfe_forward": round(nfe_f / args.steps, 1), "mean_nfe_backward": round(nfe_b / args.steps, 1)},
     }
 

@@ -72,6 +72,60 @@ def evaluate_w_distance(model, data, eval_size=100000, chunk=10000, device=None)
     return w_distance(real[:, 0], fake[:, 0])
 
 
+class GraphedTrainStep:
+    """One training iteration (forward solve, loss, adjoint solve, Adam) captured into a single hipGraph.
+
+    The reference's loop costs a host round trip per Runge-Kutta step; here a whole solve is already one kernel, and
+    what is left of an iteration on the host (a few dozen small PyTorch launches, two status read-backs) is as long
+    as the kernels themselves early in training.  Capturing the iteration removes it: replay = one graph launch.
+    Requirements: fixed batch shape, an optimizer built with capturable=True, no host sync inside (the solver status
+    is left in device memory and checked by .check()).  `warmup` eager iterations run first on a side stream (they
+    are real training steps)."""
+
+    def __init__(self, model, optimizer, example_batch, warmup_batches=()):
+        self.model, self.optimizer = model, optimizer
+        self.static_x = example_batch.clone()
+        for blk in model.chain:
+            blk.sync_stats = False
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for xb in warmup_batches:
+                self.static_x.copy_(xb)
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.check()
+        self.nfe = torch.zeros(2, dtype=torch.int64, device=example_batch.device)   # running sums: forward, backward
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._eager()
+            st = [model.chain[0].last_stats["forward"], model.chain[0].last_stats["backward"]]
+            self.nfe += torch.stack([st[0][1], st[1][1]]).to(torch.int64)
+
+    def _eager(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = compute_loss(self.model, self.static_x)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def __call__(self, x):
+        self.static_x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.static_loss
+
+    def check(self):
+        """Read the solver status words back (one sync) and raise what the eager path would have raised."""
+        from . import _native
+        for blk in self.model.chain:
+            for key in ("forward", "backward"):
+                words = blk.last_stats.get(key)
+                if torch.is_tensor(words):
+                    _native.Stats(words).raise_for_status()
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser("FFJORD CNF on the Gaussian-uniform mixture (MI355X HIP path)")
     p.add_argument("--gu_num", type=int, default=8, help="1 = unimodal, 8 = multimodal")
