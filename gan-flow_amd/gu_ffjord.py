@@ -46,7 +46,7 @@ def standard_normal_logprob(z):
 
 def compute_loss(model, x):
     """Negative mean log-likelihood of a batch under the flow."""
-    zero = torch.zeros(x.shape[0], 1).to(x)
+    zero = torch.zeros(x.shape[0], 1, device=x.device, dtype=x.dtype)
     z, delta_logp = model(x, zero)
     logpz = standard_normal_logprob(z).view(z.shape[0], -1).sum(1, keepdim=True)
     return -torch.mean(logpz - delta_logp)

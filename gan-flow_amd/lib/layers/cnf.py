@@ -84,7 +84,7 @@ class CNF(nn.Module):
         if not z.is_cuda:
             raise _native.CnfError("CNF.forward needs tensors on a HIP device (got %s): the integrator is a HIP kernel "
                                    "and has no CPU fallback" % z.device)
-        _logpz = torch.zeros(z.shape[0], 1).to(z) if logpz is None else logpz
+        _logpz = torch.zeros(z.shape[0], 1, device=z.device, dtype=z.dtype) if logpz is None else logpz
         if integration_times is None:
             t0, t1 = 0.0, self._end_time()
         else:
