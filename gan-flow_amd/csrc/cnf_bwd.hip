@@ -723,11 +723,14 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
 #pragma unroll
             for (int c = 0; c < C; ++c) yi[c] = y0[c];
         } else {
-            ti = t0f + kAlpha[stage - 1] * dtf;
+            float alpha_, bc_[6];
+            stage_coeffs(stage, alpha_, bc_);
+            ti = t0f + alpha_ * dtf;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 float s_ = 0.f;
-                for (int s = 0; s < stage; ++s) s_ += (dtf * kBeta[stage - 1][s]) * ws.kst[s][c][j];
+#pragma unroll
+                for (int s = 0; s < 6; ++s) s_ += (dtf * bc_[s]) * ws.kst[s][c][j];   // zero weights past the current stage
                 yi[c] = y0[c] + s_;
             }
         }

@@ -279,6 +279,24 @@ __device__ const float kCMid[7] = {
     (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
     (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
 
+// Row `stage` (1..6) of the tableau as compile-time literals behind a wave-uniform switch: no memory access on the
+// critical path between two evaluations (a run-time index into the __device__ tables above is a dependent load).
+__device__ __forceinline__ void stage_coeffs(int stage, float& alpha, float (&b)[6]) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) b[s] = 0.f;
+    switch (stage) {
+        case 1: alpha = (float)(1.0 / 5); b[0] = (float)(1.0 / 5); break;
+        case 2: alpha = (float)(3.0 / 10); b[0] = (float)(3.0 / 40); b[1] = (float)(9.0 / 40); break;
+        case 3: alpha = (float)(4.0 / 5); b[0] = (float)(44.0 / 45); b[1] = (float)(-56.0 / 15); b[2] = (float)(32.0 / 9); break;
+        case 4: alpha = (float)(8.0 / 9); b[0] = (float)(19372.0 / 6561); b[1] = (float)(-25360.0 / 2187);
+                b[2] = (float)(64448.0 / 6561); b[3] = (float)(-212.0 / 729); break;
+        case 5: alpha = 1.f; b[0] = (float)(9017.0 / 3168); b[1] = (float)(-355.0 / 33); b[2] = (float)(46732.0 / 5247);
+                b[3] = (float)(49.0 / 176); b[4] = (float)(-5103.0 / 18656); break;
+        default: alpha = 1.f; b[0] = (float)(35.0 / 384); b[1] = 0.f; b[2] = (float)(500.0 / 1113); b[3] = (float)(125.0 / 192);
+                b[4] = (float)(-2187.0 / 6784); b[5] = (float)(11.0 / 84); break;
+    }
+}
+
 // step-size update of the controller (Appendix B.5); time bookkeeping is float64 like the original
 __device__ __forceinline__ double next_step_size(double dt, float worst) {
     if (worst == 0.f) return dt * 10.0;

@@ -290,11 +290,14 @@ __global__ __launch_bounds__(kThreads) void dopri5_kernel(SolveArgs a) {
             phase = PH_STAGE;
         }
         // input of stage `stage` (computes slope number stage+1): y0 + sum_j (dt*beta[stage-1][j]) k_j
-        ti = t0f + kAlpha[stage - 1] * dtf;
+        float alpha_, bc_[6];
+        stage_coeffs(stage, alpha_, bc_);
+        ti = t0f + alpha_ * dtf;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float acc = 0.f;
-            for (int s = 0; s < stage; ++s) acc += (dtf * kBeta[stage - 1][s]) * ws.kst[s][c][j];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) acc += (dtf * bc_[s]) * ws.kst[s][c][j];   // zero weights past the current stage
             yi[c] = y0[c] + acc;
         }
     }
