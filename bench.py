@@ -201,9 +201,14 @@ def measure_roofline(ctx):
     st = _native.Stats(st)
     flops = args.batch * st.nfe * 3 * F_EVAL_D2
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None   # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/): not measurable in-process
+    tpath = os.path.join(ROOT, "profiles", "r01b_bwd_traffic.json")
+    if os.path.exists(tpath) and args.batch == 2048:
+        with open(tpath) as fh:
+            traffic = json.load(fh)["hbm_bytes_per_launch"]
     return {"bound": "mfma", "kernel": "dopri5_bwd_split_kernel<2,false>", "achieved": round(achieved, 4),
             "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5),
-            "traffic": None, "launch_ms": round(ms, 4), "nfe": st.nfe, "evals_run": st.evals_run, "flop_per_launch": flops}
+            "traffic": traffic, "launch_ms": round(ms, 4), "nfe": st.nfe, "evals_run": st.evals_run, "flop_per_launch": flops}
 
 
 def measure_late(ctx):
