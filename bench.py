@@ -42,7 +42,9 @@ def parse():
     p.add_argument("--eval-rows", type=int, default=1 << 20, help="rows of the sharded log-likelihood evaluation")
     p.add_argument("--late-steps", type=int, default=3)
     p.add_argument("--cpu-iters", type=int, default=12, help="oracle iterations timed for cpu_baseline (rank 0, N=1)")
-    p.add_argument("--graph", type=int, default=1, help="1: replay the training iteration as one captured hipGraph; 0: eager")
+    p.add_argument("--mode", type=str, default="fused", choices=["fused", "graph", "eager"],
+                   help="fused: gu_ffjord.FusedTrainStep (solves + cnf_nll_loss + cnf_adam_step, one hipGraph replay per "
+                        "iteration); graph: autograd + torch.optim.Adam loop captured as one hipGraph; eager: that loop, launched eagerly")
     p.add_argument("--extras", type=str, default="roofline,late,eval,cpu",
                    help="comma list of the additional measurements to run: roofline, late, eval, cpu ('' = none)")
     return p.parse_args()
@@ -118,8 +120,19 @@ def main():
     torch.manual_seed(1 + rank)
     model = gu_ffjord.build_model(2).to(dev).train()
     graphed = None
-    if args.graph:
-        # the whole iteration as one hipGraph replay (gu_ffjord.GraphedTrainStep); warm-up iterations run eagerly
+    if args.mode == "fused":
+        # library kernels only: forward solve, loss + gradient, adjoint solve, Adam; warm-up iterations are real steps
+        graphed = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=True,
+                                           warmup_batches=batches[:max(1, args.warmup)])
+        barrier()
+        t0 = time.perf_counter()
+        for x in batches[args.warmup:]:
+            graphed(x)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        nfe_f, nfe_b = [args.steps * v for v in graphed.check()]     # NFE of the last iteration (device-side words)
+    elif args.mode == "graph":
+        # the autograd loop as one hipGraph replay (gu_ffjord.GraphedTrainStep); warm-up iterations run eagerly
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
         graphed = gu_ffjord.GraphedTrainStep(model, opt, batches[0], batches[:max(1, args.warmup)])
         barrier()
@@ -154,7 +167,9 @@ def main():
                                "rtol=atol=1e-5, T=0.5, exact divergence, adjoint backward, Adam; weights from seed-1 "
                                "init (first %d iterations of training)" % (args.batch, args.warmup + args.steps),
                    "global_batch": args.batch * world, "parallelism": "independent trial per GPU (replicas only)",
-                   "launch": "hipGraph replay of the whole iteration" if graphed is not None else "eager",
+                   "launch": {"fused": "4 library kernels (fwd solve, nll loss, adjoint solve + slab reduction, Adam), one hipGraph replay per iteration",
+                              "graph": "autograd + torch.optim.Adam loop, one hipGraph replay per iteration",
+                              "eager": "autograd + torch.optim.Adam loop, eager"}[args.mode],
                    "mean_nfe_forward": round(nfe_f / args.steps, 1), "mean_nfe_backward": round(nfe_b / args.steps, 1)},
     }
 
@@ -217,15 +232,16 @@ def measure_late(ctx):
     args, world, rank, dev, batches = ctx["args"], ctx["world"], ctx["rank"], ctx["dev"], ctx["batches"]
     torch.manual_seed(1 + rank)
     late = embed_trained_multimodal(gu_ffjord.build_model(2)).to(dev).train()
-    lopt = torch.optim.Adam(late.parameters(), lr=1e-5, weight_decay=1e-5)
-    train_step(late, lopt, batches[0], gu_ffjord)
+    step = gu_ffjord.FusedTrainStep(late, batches[0], lr=1e-5, weight_decay=1e-5, graph=False)
+    step(batches[0])
     ctx["barrier"]()
     t0 = time.perf_counter()
     lf = lb = 0
     for i in range(args.late_steps):
-        _, sf, sb = train_step(late, lopt, batches[1 + i], gu_ffjord)
-        lf += sf.nfe
-        lb += sb.nfe
+        step(batches[1 + i])
+        f, b = step.check()
+        lf += f
+        lb += b
     ctx["barrier"]()
     lel = ctx["max_over_ranks"](time.perf_counter() - t0)
     return {"value": round(world * args.late_steps / lel, 4), "unit": "iters/s", "ms_per_step": round(1e3 * lel / args.late_steps, 2),

@@ -24,6 +24,11 @@ class CnfSolverOpts(ctypes.Structure):
                 ("step_size", ctypes.c_float), ("tile_rows", ctypes.c_int32), ("max_steps", ctypes.c_int32)]
 
 
+class CnfAdamOpts(ctypes.Structure):
+    _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("weight_decay", ctypes.c_double)]
+
+
 SOLVER_IDS = {"dopri5": 0, "rk4": 1}
 DIV_EXACT, DIV_HUTCHINSON = 0, 1
 STATUS_MESSAGES = {
@@ -33,7 +38,7 @@ STATUS_MESSAGES = {
     4: "grid-wide reduction timed out inside the solver kernel",
 }
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
-           "cnf_eval_aug", "cnf_solve_bwd")
+           "cnf_eval_aug", "cnf_solve_bwd", "cnf_nll_loss", "cnf_adam_step")
 
 
 def library_path():
@@ -65,6 +70,10 @@ def load_library():
     lib.cnf_eval_aug.argtypes = [ND, P, F, P, P, P, P, I64, P, P, P, P, VP, SZ, VP]
     lib.cnf_solve_bwd.restype = ctypes.c_int
     lib.cnf_solve_bwd.argtypes = [ND, P, P, P, P, P, P, I64, F, F, SO, P, P, P, VP, SZ, P, VP]
+    lib.cnf_nll_loss.restype = ctypes.c_int
+    lib.cnf_nll_loss.argtypes = [P, P, I64, ctypes.c_int32, P, P, P, VP]
+    lib.cnf_adam_step.restype = ctypes.c_int
+    lib.cnf_adam_step.argtypes = [P, P, P, P, P, I64, ctypes.POINTER(CnfAdamOpts), VP]
     _LIB = lib
     return lib
 
@@ -145,6 +154,15 @@ def make_opts(solver="dopri5", rtol=1e-5, atol=1e-5, step_size=None, tile_rows=0
     return CnfSolverOpts(SOLVER_IDS[solver], float(rtol), float(atol), float(step_size or 0.0), int(tile_rows), int(max_steps))
 
 
+def _stats_block(stats, device):
+    """The 32-byte CnfStats block a solve writes: a fresh one, or the caller's (8 contiguous int32 on `device`)."""
+    if stats is None:
+        return torch.empty(8, dtype=torch.int32, device=device)
+    if not (stats.is_cuda and stats.dtype == torch.int32 and stats.numel() == 8 and stats.is_contiguous()):
+        raise CnfError("stats must be 8 contiguous int32 words on the HIP device")
+    return stats
+
+
 def eval_field(net, params, t, z, e=None):
     """(f, -div) = ODEfunc.forward(t, (z, .)) for a (rows, dim) batch."""
     lib = load_library()
@@ -160,7 +178,7 @@ def eval_field(net, params, t, z, e=None):
     return f, nd
 
 
-def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None):
+def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None):
     """State (z, logp) at t1 of the CNF ODE started from (x, logp0) at t0.  Returns (z, logp, stats_words)."""
     lib = load_library()
     x = _dev(x, "x")
@@ -170,7 +188,7 @@ def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None):
     e = _dev(e, "e", x.shape) if e is not None else None
     z = torch.empty_like(x)
     logp = torch.empty(rows, 1, dtype=torch.float32, device=x.device)
-    stats = torch.empty(8, dtype=torch.int32, device=x.device)
+    stats = _stats_block(stats, x.device)
     with torch.cuda.device(x.device):
         ws = _workspace(lib, net, rows, x.device)
         _check(lib.cnf_solve_fwd(ctypes.byref(net), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows, float(t0), float(t1),
@@ -198,7 +216,7 @@ def eval_aug(net, params, t, z, a_z, a_logp, e=None):
     return f, nd, vz, vp
 
 
-def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None):
+def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None, stats=None):
     """Adjoint pass for the interval [t0, t1]: returns (grad_x, grad_logp0, grad_params, stats_words)."""
     lib = load_library()
     z1 = _dev(z1, "z1")
@@ -211,10 +229,40 @@ def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None)
     gx = torch.empty_like(z1)
     gl = torch.empty_like(logp1)
     gp = torch.empty_like(params)
-    stats = torch.empty(8, dtype=torch.int32, device=z1.device)
+    stats = _stats_block(stats, z1.device)
     with torch.cuda.device(z1.device):
         ws = _workspace(lib, net, rows, z1.device)
         _check(lib.cnf_solve_bwd(ctypes.byref(net), _ptr(params), _ptr(z1), _ptr(logp1), _ptr(e), _ptr(grad_z1),
                                  _ptr(grad_logp1), rows, float(t0), float(t1), ctypes.byref(opts), _ptr(gx), _ptr(gl),
                                  _ptr(gp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
     return gx, gl, gp, stats
+
+
+def nll_loss(z, delta_logp, want_grads=True):
+    """-mean(sum_d log N(z_d; 0, 1) - delta_logp) of a batch, with d loss / d z and d loss / d delta_logp.
+    Returns (loss[1], grad_z or None, grad_delta_logp or None)."""
+    lib = load_library()
+    z = _dev(z, "z")
+    rows, dim = z.shape
+    delta_logp = _dev(delta_logp, "delta_logp", (rows, 1))
+    loss = torch.empty(1, dtype=torch.float32, device=z.device)
+    gz = torch.empty_like(z) if want_grads else None
+    gl = torch.empty_like(delta_logp) if want_grads else None
+    with torch.cuda.device(z.device):
+        _check(lib.cnf_nll_loss(_ptr(z), _ptr(delta_logp), rows, dim, _ptr(loss), _ptr(gz), _ptr(gl), _stream()), lib)
+    return loss, gz, gl
+
+
+def adam_step(params, grad, exp_avg, exp_avg_sq, state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """In-place torch.optim.Adam update of a flat fp32 vector; `state` = 2 int32 on the device ({step, internal})."""
+    lib = load_library()
+    n = params.numel()
+    for name, t in (("params", params), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if _dev(t, name, (n,)).data_ptr() != t.data_ptr():
+            raise CnfError("%s must be contiguous" % name)
+    if not (torch.is_tensor(state) and state.is_cuda and state.dtype == torch.int32 and state.numel() == 2):
+        raise CnfError("state must be 2 int32 words on the HIP device")
+    o = CnfAdamOpts(float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay))
+    with torch.cuda.device(params.device):
+        _check(lib.cnf_adam_step(_ptr(params), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(state), n,
+                                 ctypes.byref(o), _stream()), lib)

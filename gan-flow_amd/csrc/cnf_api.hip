@@ -16,6 +16,10 @@ hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
 hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 hipError_t launch_split_aug(int D, bool hutch, const SolveArgs& a, float t, const float* z, const float* a_z,
                             const float* a_l, float* f_out, float* nd_out, float* vz_out, hipStream_t s);
+// loss and optimizer step, cnf_train.hip
+hipError_t launch_nll_loss(const float* z, const float* dlogp, long rows, int dim, float* loss_out, float* grad_z,
+                           float* grad_dlogp, hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state, long n, const CnfAdamOpts& o, hipStream_t s);
 }  // namespace cnf
 
 namespace {
@@ -223,6 +227,28 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
     if (err == hipSuccess) err = use_split(net, rows) ? cnf::launch_split_bwd(net->dim, hutch, a, s) : cnf::launch_solve_bwd(net->dim, hutch, a, s);
     if (err != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int cnf_nll_loss(const float* z, const float* delta_logp, int64_t rows, int32_t dim, float* loss_out, float* grad_z,
+                 float* grad_delta_logp, void* stream) {
+    if (!z || !delta_logp || !loss_out) return fail("cnf_nll_loss: NULL pointer");
+    if (rows <= 0 || dim <= 0) return fail("cnf_nll_loss: rows and dim must be positive (got %ld, %d)", (long)rows, dim);
+    hipError_t err = cnf::launch_nll_loss(z, delta_logp, rows, dim, loss_out, grad_z, grad_delta_logp, (hipStream_t)stream);
+    if (err != hipSuccess) return fail("cnf_nll_loss: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int cnf_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* state, int64_t n,
+                  const CnfAdamOpts* opts, void* stream) {
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !state || !opts) return fail("cnf_adam_step: NULL pointer");
+    if (n <= 0) return fail("cnf_adam_step: n must be positive (got %ld)", (long)n);
+    if (!(opts->lr >= 0.) || !(opts->beta1 >= 0. && opts->beta1 < 1.) || !(opts->beta2 >= 0. && opts->beta2 < 1.) ||
+        !(opts->eps >= 0.) || !(opts->weight_decay >= 0.))
+        return fail("cnf_adam_step: invalid hyper-parameters (lr %g, betas %g %g, eps %g, weight_decay %g)", opts->lr,
+                    opts->beta1, opts->beta2, opts->eps, opts->weight_decay);
+    hipError_t err = cnf::launch_adam(params, grad, exp_avg, exp_avg_sq, state, n, *opts, (hipStream_t)stream);
+    if (err != hipSuccess) return fail("cnf_adam_step: launch failed: %s", hipGetErrorString(err));
     return 0;
 }
 

@@ -126,6 +126,111 @@ class GraphedTrainStep:
                     _native.Stats(words).raise_for_status()
 
 
+class FusedTrainStep:
+    """One training iteration with nothing but the library's kernels in it:
+
+        forward solve(s) -> cnf_nll_loss (loss + its gradient) -> adjoint solve(s) -> cnf_adam_step
+
+    i.e. 4 kernels (+ the slab reduction) per CNF block instead of the ~100 launches that autograd, the loss
+    expression and torch.optim.Adam add around the two solves.  The arithmetic is that of
+    `loss = compute_loss(model, x); loss.backward(); Adam(lr, betas, eps, weight_decay).step()`; the parameters
+    are updated in place through ODEnet.flatten_parameters(), so `model` (state_dict, evaluation) always sees the
+    trained weights.  As in the reference, `sqrt_end_time` receives no gradient (T enters the solve detached).
+    With graph=True the iteration is captured once and replayed as one hipGraph; the solver status words stay on the
+    device until .check()."""
+
+    def __init__(self, model, example_batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, graph=True,
+                 warmup_batches=()):
+        from . import _native
+        from .lib.layers.cnf import _inner
+        self._native, self.model = _native, model
+        self.hyper = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.blocks = list(model.chain)
+        for blk in self.blocks:
+            if not isinstance(blk, CNF) or blk.nreg:
+                raise NotImplementedError("FusedTrainStep handles a SequentialFlow of CNF blocks without regularisers")
+        self.nets = [_inner(blk.odefunc).diffeq for blk in self.blocks]
+        self.flats = [net.flatten_parameters() for net in self.nets]
+        self.exp_avg = [torch.zeros_like(f) for f in self.flats]
+        self.exp_avg_sq = [torch.zeros_like(f) for f in self.flats]
+        dev = example_batch.device
+        self.adam_state = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in self.flats]
+        self.stats = torch.zeros(len(self.blocks), 2, 8, dtype=torch.int32, device=dev)   # [block][fwd, bwd][CnfStats words]
+        self.static_x = example_batch.clone()
+        self.static_loss = None
+        self.graph = None
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for xb in warmup_batches:
+                    self.static_x.copy_(xb)
+                    self._iteration()
+                if not len(warmup_batches):          # capture needs the library loaded and the workspace allocated
+                    self._dry_run()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.check()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_loss = self._iteration()
+        else:
+            for xb in warmup_batches:
+                self.static_x.copy_(xb)
+                self._iteration()
+
+    def _dry_run(self):
+        """A forward + adjoint solve that changes nothing (sizes the cached workspace before capture)."""
+        saved = [f.clone() for f in self.flats], [s.clone() for s in self.adam_state]
+        m, v = [t.clone() for t in self.exp_avg], [t.clone() for t in self.exp_avg_sq]
+        self._iteration()
+        for dst, src in zip(self.flats + self.adam_state + self.exp_avg + self.exp_avg_sq, saved[0] + saved[1] + m + v):
+            dst.copy_(src)
+
+    def _iteration(self):
+        nat = self._native
+        z, lp, tape = self.static_x, None, []
+        for i, blk in enumerate(self.blocks):
+            net, t0, t1, opts, e = blk.solve_plan(z, reset_counter=False)
+            z, lp, _ = nat.solve_fwd(net, self.flats[i], z, lp, t0, t1, opts, e, stats=self.stats[i, 0])
+            tape.append((net, t0, t1, opts, e, z, lp))
+        loss, gz, gl = nat.nll_loss(z, lp)
+        for i in range(len(self.blocks) - 1, -1, -1):
+            net, t0, t1, opts, e, z1, lp1 = tape[i]
+            gz, gl, gp, _ = nat.solve_bwd(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, e, stats=self.stats[i, 1])
+            nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], **self.hyper)
+        return loss
+
+    def __call__(self, x):
+        self.static_x.copy_(x, non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+            return self.static_loss
+        return self._iteration()
+
+    def check(self):
+        """Read the solver status words of the last iteration back (one sync), raise what the eager path would have
+        raised, refresh the modules' evaluation counters, and make sure the parameters still alias the flat buffers.
+        Returns (nfe_forward, nfe_backward) of the last iteration, summed over blocks."""
+        from .lib.layers.cnf import _inner
+        words = self.stats.cpu()
+        nfe = [0, 0]
+        for i, blk in enumerate(self.blocks):
+            for k in (0, 1):
+                st = self._native.Stats(words[i, k])
+                st.raise_for_status()
+                nfe[k] += st.nfe
+            _inner(blk.odefunc)._num_evals.fill_(float(words[i, 0, 1] + words[i, 1, 1] + 1))
+            if not self.nets[i].flat_is_current():
+                raise RuntimeError("the ODEnet's parameters no longer alias the flat buffer FusedTrainStep updates "
+                                   "(module moved or re-assigned?): build a new FusedTrainStep")
+        return tuple(nfe)
+
+    @property
+    def step_count(self):
+        return int(self.adam_state[0][0].item())
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser("FFJORD CNF on the Gaussian-uniform mixture (MI355X HIP path)")
     p.add_argument("--gu_num", type=int, default=8, help="1 = unimodal, 8 = multimodal")
@@ -147,6 +252,8 @@ def parse_args(argv=None):
     p.add_argument("--eval_size", type=int, default=100000)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--save", type=str, default="experiments/gu_ffjord")
+    p.add_argument("--fused", type=int, default=1, help="1: FusedTrainStep (library kernels only, one hipGraph replay per "
+                   "iteration); 0: autograd + torch.optim.Adam loop")
     return p.parse_args(argv)
 
 
@@ -167,22 +274,33 @@ def main(argv=None):
         for block in model.chain:
             block.solver_options["step_size"] = args.step_size
     logger.info("parameters: %d" % count_parameters(model))
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     model.train()
+    fused = optimizer = None
+    if args.fused:
+        x = data.get_sample(args.batch_size).to(device)
+        fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     t_last = time.time()
     for itr in range(1, args.niters + 1):
-        optimizer.zero_grad(set_to_none=True)
         x = data.get_sample(args.batch_size).to(device)
-        loss = compute_loss(model, x)
-        nfe_f = count_nfe(model)
-        loss.backward()
-        nfe_t = count_nfe(model)
-        optimizer.step()
-        if itr % args.log_interval == 0 or itr == 1:
+        log_now = itr % args.log_interval == 0 or itr == 1
+        if fused is not None:
+            loss = fused(x)
+            if log_now:
+                nfe_f, nfe_b = fused.check()
+        else:
+            optimizer.zero_grad(set_to_none=True)
+            loss = compute_loss(model, x)
+            nfe_f = count_nfe(model)
+            loss.backward()
+            nfe_b = count_nfe(model) - nfe_f
+            optimizer.step()
+        if log_now:
             now = time.time()
             wd = evaluate_w_distance(model, data, args.eval_size, device=device)
             logger.info("iter %06d | loss %.6f | NFE fwd %d bwd %d | %.3f s/iter (incl. logging) | W-distance %.4f"
-                        % (itr, loss.item(), nfe_f, nfe_t - nfe_f, (now - t_last) / max(1, args.log_interval if itr > 1 else 1), wd))
+                        % (itr, loss.item(), nfe_f, nfe_b, (now - t_last) / max(1, args.log_interval if itr > 1 else 1), wd))
             torch.save(model.state_dict(), os.path.join(args.save, "ffjord_state_dict.pth"))
             t_last = time.time()
     return model

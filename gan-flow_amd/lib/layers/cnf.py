@@ -80,11 +80,13 @@ class CNF(nn.Module):
         else:
             self.last_stats[key] = stats_words
 
-    def forward(self, z, logpz=None, integration_times=None, reverse=False):
+    def solve_plan(self, z, integration_times=None, reverse=False, reset_counter=True):
+        """What one solve of this block needs, as plain values: (net, t0, t1, opts, e).  Also resets the evaluation
+        counter / Hutchinson probe the way the reference's CNF.forward does (before_odeint); reset_counter=False
+        drops the probe only (no device work: for callers that keep the counter themselves)."""
         if not z.is_cuda:
             raise _native.CnfError("CNF.forward needs tensors on a HIP device (got %s): the integrator is a HIP kernel "
                                    "and has no CPU fallback" % z.device)
-        _logpz = torch.zeros(z.shape[0], 1, device=z.device, dtype=z.dtype) if logpz is None else logpz
         if integration_times is None:
             t0, t1 = 0.0, self._end_time()
         else:
@@ -93,16 +95,22 @@ class CNF(nn.Module):
             t0, t1 = float(integration_times[0]), float(integration_times[1])
         if reverse:
             t0, t1 = t1, t0
-        self.odefunc.before_odeint()
         inner = _inner(self.odefunc)
+        if reset_counter:
+            self.odefunc.before_odeint()
+        else:
+            inner._e = None
         if self.training:
             solver, atol, rtol, options = self.solver, self.atol, self.rtol, self.solver_options
         else:
             solver, atol, rtol, options = self.test_solver, self.test_atol, self.test_rtol, {}
         opts = _native.make_opts(solver, rtol, atol, options.get("step_size"), self.tile_rows, options.get("max_num_steps", 0))
-        net = inner.net_desc()
-        e = inner.probe(z)
-        flat = inner.diffeq.flat_parameters()
+        return inner.net_desc(), t0, t1, opts, inner.probe(z)
+
+    def forward(self, z, logpz=None, integration_times=None, reverse=False):
+        net, t0, t1, opts, e = self.solve_plan(z, integration_times, reverse)
+        _logpz = torch.zeros(z.shape[0], 1, device=z.device, dtype=z.dtype) if logpz is None else logpz
+        flat = _inner(self.odefunc).diffeq.flat_parameters()
         z_t, logpz_t = _Solve.apply(z, _logpz, flat, self, t0, t1, opts, net, e)
         self.regularization_states = ()
         return (z_t, logpz_t) if logpz is not None else z_t

@@ -42,6 +42,32 @@ class ODEnet(nn.Module):
         """The parameter vector in the order include/cnf_hip.h documents (== self.parameters() order)."""
         return torch.cat([p.reshape(-1) for p in self.parameters()])
 
+    def flatten_parameters(self):
+        """Move the parameters into ONE contiguous buffer laid out as the kernels read it and make every
+        nn.Parameter a view of its slice (names, shapes and state_dict are unchanged).  Returns the buffer: an update
+        written to it (gu_ffjord.FusedTrainStep) is an update of the module's parameters.  `.to()` / `.cuda()` /
+        load_state_dict(assign=True) re-allocate parameters: call again afterwards (flat_is_current() tells)."""
+        ps = list(self.parameters())
+        flat = torch.cat([p.detach().reshape(-1) for p in ps])
+        off = 0
+        for p in ps:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self._flat = flat
+        return flat
+
+    def flat_is_current(self):
+        flat = getattr(self, "_flat", None)
+        if flat is None:
+            return False
+        addr = flat.data_ptr()
+        for p in self.parameters():
+            if p.data_ptr() != addr or p.device != flat.device:
+                return False
+            addr += 4 * p.numel()
+        return True
+
     def forward(self, t, y):
         h = y
         last = len(self.layers) - 1

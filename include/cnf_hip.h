@@ -119,6 +119,27 @@ int cnf_solve_bwd(const CnfNetDesc *net, const float *params, const float *z1, c
                   float *grad_params, void *workspace, size_t workspace_bytes, CnfStats *stats,
                   void *stream);
 
+/* Negative mean log-likelihood of a batch under the flow and its gradient w.r.t. the solver outputs: the
+ * reference's training loss (standard_normal_logprob(z).sum(1) - delta_logp, loss = -mean;
+ * run as `python3 -m ffjord.gu_maf`, /root/reference/README.md:41,57).
+ *   z (rows x dim), delta_logp (rows): outputs of cnf_solve_fwd;  loss_out: 1 float (device);
+ *   grad_z (rows x dim) = z / rows and grad_delta_logp (rows) = 1 / rows, either may be NULL.
+ * Deterministic (fixed summation order).                                                                 */
+int cnf_nll_loss(const float *z, const float *delta_logp, int64_t rows, int32_t dim, float *loss_out,
+                 float *grad_z, float *grad_delta_logp, void *stream);
+
+/* Adam on a flat parameter vector, the update the reference's driver applies with torch.optim.Adam
+ * (lr 1e-3, weight_decay 1e-5 added to the gradient).                 */
+typedef struct CnfAdamOpts {
+    double lr, beta1, beta2, eps, weight_decay; /* doubles, as torch holds them: 1 - beta is formed in double */
+} CnfAdamOpts;
+
+/*   params, exp_avg, exp_avg_sq (n floats each) are updated in place from grad (n floats);
+ *   state: 2 int32 in device memory, zeroed by the caller before the first step: {step count, internal};
+ *   the step count is read and incremented on the device, so the call can be captured in a hipGraph.    */
+int cnf_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, int32_t *state,
+                  int64_t n, const CnfAdamOpts *opts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

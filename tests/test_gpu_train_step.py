@@ -1,0 +1,128 @@
+"""GPU tests of the loss and optimizer kernels (cnf_nll_loss, cnf_adam_step) and of
+gu_ffjord.FusedTrainStep, the training iteration built from library kernels only.  References: the oracle's loss
+expression (oracle/layers.py, CPU) and torch.optim.Adam on the CPU; the fused iteration is compared with the
+autograd + torch.optim.Adam loop over the same HIP solves."""
+import pytest
+import torch
+
+import oracle
+from _helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _native():
+    from gan_flow_amd import _native
+    _native.load_library()
+    return _native
+
+
+@pytest.mark.parametrize("rows,dim", [(2048, 2), (1, 1), (1000, 16), (70001, 2)])
+def test_nll_loss_and_gradient(rows, dim):
+    nat = _native()
+    g = torch.Generator().manual_seed(rows + dim)
+    z = (torch.randn(rows, dim, generator=g) * 1.7).requires_grad_(True)
+    dl = torch.randn(rows, 1, generator=g).requires_grad_(True)
+    ref = -torch.mean(oracle.layers.standard_normal_logprob(z).view(rows, -1).sum(1, keepdim=True) - dl)
+    ref.backward()
+    loss, gz, gl = nat.nll_loss(z.detach().to(DEV), dl.detach().to(DEV))
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    assert rel_err(gz, z.grad) < 1e-6 and rel_err(gl, dl.grad) < 1e-6
+    loss2, none_z, none_l = nat.nll_loss(z.detach().to(DEV), dl.detach().to(DEV), want_grads=False)
+    assert none_z is None and none_l is None and loss2.item() == loss.item()      # deterministic
+
+
+@pytest.mark.parametrize("n,wd", [(9224, 1e-5), (300, 0.0), (200003, 1e-2)])
+def test_adam_step_matches_torch_optim(n, wd):
+    nat = _native()
+    g = torch.Generator().manual_seed(n)
+    p_ref = torch.nn.Parameter(torch.randn(n, generator=g))
+    opt = torch.optim.Adam([p_ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    p = p_ref.detach().clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    for it in range(6):
+        grad = torch.randn(n, generator=g) * (10.0 ** (it - 3))
+        p_ref.grad = grad.clone()
+        opt.step()
+        nat.adam_step(p, grad.to(DEV), m, v, state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    st = opt.state[p_ref]
+    assert state.tolist() == [6, 0]
+    assert torch.allclose(p.cpu(), p_ref.detach(), rtol=1e-6, atol=1e-7)
+    assert rel_err(m, st["exp_avg"]) < 1e-6 and rel_err(v, st["exp_avg_sq"]) < 1e-6
+    assert torch.allclose(v.cpu(), st["exp_avg_sq"], rtol=2e-6, atol=0)
+
+
+def test_adam_step_rejects_bad_arguments():
+    nat = _native()
+    p = torch.zeros(8, device=DEV)
+    st = torch.zeros(2, dtype=torch.int32, device=DEV)
+    with pytest.raises(nat.CnfError):
+        nat.adam_step(p, p.clone(), p.clone(), p.clone(), st, betas=(1.0, 0.999))
+    with pytest.raises(nat.CnfError):
+        nat.adam_step(p, torch.zeros(7, device=DEV), p.clone(), p.clone(), st)
+    with pytest.raises(nat.CnfError):
+        nat.adam_step(p, p.clone(), p.clone(), p.clone(), torch.zeros(2, dtype=torch.int64, device=DEV))
+
+
+@pytest.mark.parametrize("graph,blocks", [(False, 1), (True, 1), (False, 2)])
+def test_fused_train_step_matches_autograd_loop(graph, blocks):
+    """Same batches, same initial weights: the fused iteration follows the trajectory of compute_loss / backward /
+    torch.optim.Adam (which run the same solves) to rounding, and keeps the module's parameters up to date."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    data = make_gu(8, seed=3)
+    batches = [data.get_sample(2048).to(DEV) for _ in range(8)]
+
+    torch.manual_seed(5)
+    ref = gu_ffjord.build_model(2, num_blocks=blocks).to(DEV).train()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-5)
+    ref_losses = []
+    for x in batches:
+        opt.zero_grad(set_to_none=True)
+        loss = gu_ffjord.compute_loss(ref, x)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    nfe_ref = (sum(b.last_stats["forward"].nfe for b in ref.chain), sum(b.last_stats["backward"].nfe for b in ref.chain))
+
+    torch.manual_seed(5)
+    model = gu_ffjord.build_model(2, num_blocks=blocks).to(DEV).train()
+    t_before = model.chain[0].sqrt_end_time.detach().clone()
+    step = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=graph)
+    losses = [step(x).item() for x in batches]
+    nfe = step.check()
+    print("reference", ["%.5f" % v for v in ref_losses])
+    print("fused    ", ["%.5f" % v for v in losses])
+    assert step.step_count == len(batches)
+    assert nfe == nfe_ref
+    assert all(abs(a - b) <= 2e-5 * abs(a) for a, b in zip(ref_losses, losses))
+    pr = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    pf = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    print("max |dp| %.3e (updates moved the weights by %.3e)" % ((pr - pf).abs().max().item(), 8e-3))
+    assert (pr - pf).abs().max().item() < 5e-5
+    assert torch.equal(model.chain[0].sqrt_end_time.detach(), t_before)       # T gets no gradient, as in the reference
+    # the module evaluates with the trained weights (parameters are views of the updated buffer)
+    model.eval()
+    ref.eval()
+    xe = batches[0][:256]
+    z1, dl1 = model(xe, torch.zeros(256, 1, device=DEV))
+    z2, dl2 = ref(xe, torch.zeros(256, 1, device=DEV))
+    assert rel_err(z1, z2) < 1e-4 and rel_err(dl1, dl2) < 1e-3
+    assert model.chain[0].num_evals() > 0
+
+
+def test_fused_train_step_two_blocks_hutchinson():
+    """Stacked blocks + Hutchinson divergence: the loss gradient is chained through the blocks in reverse."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    data = make_gu(8, seed=4)
+    batches = [data.get_sample(1024).to(DEV) for _ in range(12)]
+    torch.manual_seed(2)
+    model = gu_ffjord.build_model(2, num_blocks=2, divergence_fn="approximate").to(DEV).train()
+    step = gu_ffjord.FusedTrainStep(model, batches[0], lr=2e-3, graph=False)
+    losses = [step(x).item() for x in batches]
+    step.check()
+    print("two-block losses", ["%.3f" % v for v in losses])
+    assert all(torch.isfinite(torch.tensor(losses))) and min(losses[-3:]) < losses[0]
