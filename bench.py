@@ -45,8 +45,8 @@ def parse():
     p.add_argument("--mode", type=str, default="fused", choices=["fused", "graph", "eager"],
                    help="fused: gu_ffjord.FusedTrainStep (solves + cnf_nll_loss + cnf_adam_step, one hipGraph replay per "
                         "iteration); graph: autograd + torch.optim.Adam loop captured as one hipGraph; eager: that loop, launched eagerly")
-    p.add_argument("--extras", type=str, default="roofline,late,eval,cpu",
-                   help="comma list of the additional measurements to run: roofline, late, eval, cpu ('' = none)")
+    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,cpu",
+                   help="comma list of the additional measurements to run: roofline, late, eval, d16, cpu ('' = none)")
     return p.parse_args()
 
 
@@ -182,6 +182,8 @@ def main():
         out["late_training"] = measure_late(ctx)
     if "eval" in extras:
         out["eval"] = measure_eval(ctx)
+    if "d16" in extras:
+        out["d16_hutchinson"] = measure_d16(ctx)
     if "cpu" in extras and rank == 0 and world == 1 and args.cpu_iters > 0:
         out["cpu_baseline"] = measure_cpu(ctx)
 
@@ -247,6 +249,31 @@ def measure_late(ctx):
     return {"value": round(world * args.late_steps / lel, 4), "unit": "iters/s", "ms_per_step": round(1e3 * lel / args.late_steps, 2),
             "mean_nfe_forward": round(lf / args.late_steps, 1), "mean_nfe_backward": round(lb / args.late_steps, 1),
             "workload": "same step on the reference's trained gu_num=8 field (checkpoint weights embedded in d=2)"}
+
+
+def measure_d16(ctx):
+    """BASELINE config 5: d=16 Gaussian mixture, Hutchinson divergence, B=2048, one independent seed per GPU."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gmm import GaussianMixture
+    args, world, rank, dev = ctx["args"], ctx["world"], ctx["rank"], ctx["dev"]
+    data = GaussianMixture(16, device=dev, sample_seed=1 + rank)
+    torch.manual_seed(1 + rank)
+    model = gu_ffjord.build_model(16, divergence_fn="approximate").to(dev).train()
+    xs = [data.get_sample(args.batch) for _ in range(args.warmup + args.steps)]
+    step = gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True,
+                                    warmup_batches=xs[:max(1, args.warmup)])
+    ctx["barrier"]()
+    t0 = time.perf_counter()
+    for x in xs[args.warmup:]:
+        step(x)
+    ctx["barrier"]()
+    el = ctx["max_over_ranks"](time.perf_counter() - t0)
+    nfe_f, nfe_b = step.check()
+    return {"value": round(world * args.steps / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+            "nfe_forward": nfe_f, "nfe_backward": nfe_b, "scaling": "weak",
+            "workload": "FFJORD CNF on the synthetic d=16 8-component Gaussian mixture, B=%d, ODEnet 16-64-64-64-16, "
+                        "Hutchinson divergence (Gaussian probe, fresh per iteration), dopri5 1e-5, adjoint, Adam; "
+                        "seed 1+rank per GPU" % args.batch}
 
 
 def measure_eval(ctx):

@@ -38,7 +38,7 @@ STATUS_MESSAGES = {
     4: "grid-wide reduction timed out inside the solver kernel",
 }
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
-           "cnf_eval_aug", "cnf_solve_bwd", "cnf_nll_loss", "cnf_adam_step")
+           "cnf_eval_aug", "cnf_solve_bwd", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds")
 
 
 def library_path():
@@ -74,6 +74,8 @@ def load_library():
     lib.cnf_nll_loss.argtypes = [P, P, I64, ctypes.c_int32, P, P, P, VP]
     lib.cnf_adam_step.restype = ctypes.c_int
     lib.cnf_adam_step.argtypes = [P, P, P, P, P, I64, ctypes.POINTER(CnfAdamOpts), VP]
+    lib.cnf_debug_fill_lds.restype = ctypes.c_int
+    lib.cnf_debug_fill_lds.argtypes = [ctypes.c_uint32, P, VP]
     _LIB = lib
     return lib
 
@@ -266,3 +268,13 @@ def adam_step(params, grad, exp_avg, exp_avg_sq, state, lr=1e-3, betas=(0.9, 0.9
     with torch.cuda.device(params.device):
         _check(lib.cnf_adam_step(_ptr(params), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(state), n,
                                  ctypes.byref(o), _stream()), lib)
+
+
+def debug_fill_lds(pattern=0x7FC00000, device=None):
+    """Diagnostics: overwrite the LDS of every CU with `pattern` (default: a quiet NaN)."""
+    lib = load_library()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    word = torch.zeros(1, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        _check(lib.cnf_debug_fill_lds(int(pattern), _ptr(word), _stream()), lib)
+    return word

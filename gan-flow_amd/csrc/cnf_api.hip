@@ -20,6 +20,7 @@ hipError_t launch_split_aug(int D, bool hutch, const SolveArgs& a, float t, cons
 hipError_t launch_nll_loss(const float* z, const float* dlogp, long rows, int dim, float* loss_out, float* grad_z,
                            float* grad_dlogp, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state, long n, const CnfAdamOpts& o, hipStream_t s);
+hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s);
 }  // namespace cnf
 
 namespace {
@@ -57,7 +58,14 @@ long n_wg(long rows) { return (rows + cnf::kRowsPerWG - 1) / cnf::kRowsPerWG; }
 
 // batch-global solves of up to 16*256 rows run one tile per workgroup (cnf_split.hip): every workgroup resident
 bool use_split(const CnfNetDesc* n, long rows) {
-    return n->dim <= 2 && rows <= (long)cnf::kRows * cnf::kMaxWG;
+    return rows <= (long)cnf::kRows * cnf::kMaxWG;
+}
+// the one-tile-per-wave adjoint kernels (rows > 4096) exist for dim <= 2 only
+int check_adjoint_rows(const char* who, const CnfNetDesc* n, long rows) {
+    if (n->dim > 2 && !use_split(n, rows))
+        return fail("%s: the adjoint for dim=%d supports at most %d rows per call (got %ld)", who, n->dim,
+                    cnf::kRows * cnf::kMaxWG, rows);
+    return 0;
 }
 long n_slabs(const CnfNetDesc* n, long rows) {
     return use_split(n, rows) ? (rows + cnf::kRows - 1) / cnf::kRows : n_wg(rows);
@@ -184,6 +192,7 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
     if (workspace_bytes < need) return fail("cnf_eval_aug: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
     const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
     if (hutch && !e) return fail("cnf_eval_aug: Hutchinson divergence needs the probe e");
+    if (check_adjoint_rows("cnf_eval_aug", net, rows)) return 1;
     cnf::SolveArgs a{};
     a.params = params;
     a.rows = rows;
@@ -214,6 +223,7 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     if (!global) return fail("cnf_solve_bwd: the adjoint pass needs batch-global step control (tile_rows = 0)");
     const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
     if (hutch && !e) return fail("cnf_solve_bwd: Hutchinson divergence needs the probe e");
+    if (check_adjoint_rows("cnf_solve_bwd", net, rows)) return 1;
     a.x = z1;
     a.logp0 = logp1;
     a.e = e;
@@ -249,6 +259,13 @@ int cnf_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
                     opts->beta1, opts->beta2, opts->eps, opts->weight_decay);
     hipError_t err = cnf::launch_adam(params, grad, exp_avg, exp_avg_sq, state, n, *opts, (hipStream_t)stream);
     if (err != hipSuccess) return fail("cnf_adam_step: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int cnf_debug_fill_lds(uint32_t pattern, uint32_t* scratch_word, void* stream) {
+    if (!scratch_word) return fail("cnf_debug_fill_lds: NULL pointer");
+    hipError_t err = cnf::launch_fill_lds(pattern, scratch_word, (hipStream_t)stream);
+    if (err != hipSuccess) return fail("cnf_debug_fill_lds: launch failed: %s", hipGetErrorString(err));
     return 0;
 }
 

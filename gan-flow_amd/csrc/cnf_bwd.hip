@@ -539,6 +539,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
     if (tid == 0) red.status = 0;
     stage_net(net, a.params, tid);
     stage_net_T<D>(netT, a.params, tid);
+    zero_slopes(wl, kNW, tid);
     __syncthreads();
     const long base = ((long)blockIdx.x * kNW + w) * kRows;
     const long row = base + j;

@@ -297,6 +297,18 @@ __device__ __forceinline__ void stage_coeffs(int stage, float& alpha, float (&b)
     }
 }
 
+// stage_coeffs multiplies the slopes of stages that have not been evaluated yet by a zero weight, so those slots must
+// hold finite numbers from the start: LDS keeps whatever the previous kernel on the CU left there, and 0 * NaN = NaN.
+// Call before the kernel's first workgroup barrier; `n_ws` = number of per-wave blocks in `wl`.
+template <class WS>
+__device__ __forceinline__ void zero_slopes(WS* wl, int n_ws, int tid) {
+    constexpr int n = (int)(sizeof(wl[0].kst) / sizeof(float));
+    for (int i = 0; i < n_ws; ++i) {
+        float* k = &wl[i].kst[0][0][0];
+        for (int idx = tid; idx < n; idx += kThreads) k[idx] = 0.f;
+    }
+}
+
 // step-size update of the controller (Appendix B.5); time bookkeeping is float64 like the original
 __device__ __forceinline__ double next_step_size(double dt, float worst) {
     if (worst == 0.f) return dt * 10.0;

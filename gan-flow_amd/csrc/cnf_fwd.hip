@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_kernel(SolveArgs a) {
     constexpr int C = D + 1;
     if (tid == 0) red.status = 0;
     stage_net(net, a.params, tid);
+    zero_slopes(wl, kNW, tid);
     __syncthreads();
     const long base = ((long)blockIdx.x * kNW + w) * kRows;
     if (!GLOBAL && base >= a.rows) return;

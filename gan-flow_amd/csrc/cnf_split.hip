@@ -16,7 +16,14 @@
 
 namespace cnf {
 
-constexpr int kNSMax = 3;
+// streams a tile carries: value + tangents.  d <= 2: up to 2 exact tangents; d = 16 is Hutchinson only (one tangent)
+template <int D>
+constexpr int kNSMaxOf = D > 2 ? 2 : 3;
+// d = 16 adjoint: the four waves share ONE copy of the gates and of the Runge-Kutta slopes (they hold identical
+// values and every reader is separated from the next evaluation's writers by a workgroup barrier); 4 copies of
+// kst[7][33][16] would not fit next to the weight images in 160 KB.
+template <int D>
+constexpr bool kShareWaveLds = D > 2;
 
 template <int C>
 struct alignas(16) SplitWaveLds {
@@ -27,7 +34,7 @@ struct alignas(16) SplitWaveLds {
 
 template <int D>
 struct alignas(16) SplitXchg {
-    float xb[2][kNSMax][4][64][4];   // activations / cotangents in C-D layout: [buffer][stream][feature tile][lane][r]
+    float xb[2][kNSMaxOf<D>][4][64][4];   // activations / cotangents in C-D layout: [buffer][stream][feature tile][lane][r]
     float part[kNW][2 * D][kRows];   // layer-4 partial sums of every wave
 };
 
@@ -154,6 +161,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
     stage_net(net, a.params, tid);
+    zero_slopes(wl, kNW, tid);
     __syncthreads();
     const long row = (long)blockIdx.x * kRows + j;
     const bool counted = row < a.rows && lane < 16 && w == 0;   // every wave carries the same 16 rows: count them once
@@ -353,8 +361,8 @@ struct SmallIdxS {   // parameters other than the two 64x64 matrices, canonical 
 template <int D>
 struct alignas(16) SplitBwdLds {
     float wimgT[2][16][64][4];            // as BwdNetLds::wimgT
-    float trB[2][kNSMax][kH * kRows];     // transposed layer inputs, all 64 features: [buffer][stream][feature*16 + pos(row)]
-    float trA[kNW][kNSMax][16 * kRows];   // per wave: transposed, weighted cotangents of its own 16 features
+    float trB[2][kNSMaxOf<D>][kH * kRows];     // transposed layer inputs, all 64 features: [buffer][stream][feature*16 + pos(row)]
+    float trA[kNW][kNSMaxOf<D>][16 * kRows];   // per wave: transposed, weighted cotangents of its own 16 features
     float small[SmallIdxS<D>::padded];    // the step's d/dtheta of the small parameters (waves own disjoint features)
     float part2[kNW][D][kRows];           // vjp_z partial sums of every wave
     float wq[8];                          // quadrature weights of the current attempt
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     constexpr int C = 2 * D + 1;
     __shared__ NetLds<D> net;
     __shared__ SplitBwdLds<D> sb;
-    __shared__ SplitWaveLds<C> wl[kNW];
+    __shared__ SplitWaveLds<C> wl[kShareWaveLds<D> ? 1 : kNW];
     __shared__ SplitXchg<D> xc;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     stage_net(net, a.params, tid);
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     const float al = valid ? a_l[rr] : 0.f;
     BigAccS acc;
     acc.zero();
-    aug_eval_split<D, HUTCH>(net, sb, wl[w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc);
+    aug_eval_split<D, HUTCH>(net, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc);
     if (w == 0 && lane < 16 && valid) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -748,19 +756,20 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     constexpr int CE = D + 1;
     __shared__ NetLds<D> net;
     __shared__ SplitBwdLds<D> sb;
-    __shared__ SplitWaveLds<C> wl[kNW];
+    __shared__ SplitWaveLds<C> wl[kShareWaveLds<D> ? 1 : kNW];
     __shared__ SplitXchg<D> xc;
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
     stage_net(net, a.params, tid);
     stage_wimgT<D>(&sb.wimgT[0][0][0][0], a.params, tid);
+    zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid);
     __syncthreads();
     const long row = (long)blockIdx.x * kRows + j;
     const bool valid = row < a.rows;
     const bool counted = valid && lane < 16 && w == 0;
     const long rr = valid ? row : a.rows - 1;
-    SplitWaveLds<C>& ws = wl[w];
+    SplitWaveLds<C>& ws = wl[kShareWaveLds<D> ? 0 : w];
     float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;
 
     GridSync gs{a.gran, (int)gridDim.x, 0u};
@@ -1003,6 +1012,7 @@ hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
     if (D == 1 && !hutch) return split_fwd_t<1, false>(a, s);
     if (D == 2 && !hutch) return split_fwd_t<2, false>(a, s);
     if (D == 2 && hutch) return split_fwd_t<2, true>(a, s);
+    if (D == 16 && hutch) return split_fwd_t<16, true>(a, s);
     return hipErrorNotSupported;
 }
 
@@ -1021,6 +1031,7 @@ hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
     if (D == 1 && !hutch) return split_bwd_t<1, false>(a, s);
     if (D == 2 && !hutch) return split_bwd_t<2, false>(a, s);
     if (D == 2 && hutch) return split_bwd_t<2, true>(a, s);
+    if (D == 16 && hutch) return split_bwd_t<16, true>(a, s);
     return hipErrorNotSupported;
 }
 
@@ -1041,6 +1052,7 @@ hipError_t launch_split_aug(int D, bool hutch, const SolveArgs& a, float t, cons
     if (D == 1 && !hutch) return split_aug_t<1, false>(a, t, z, a_z, a_l, f_out, nd_out, vz_out, s);
     if (D == 2 && !hutch) return split_aug_t<2, false>(a, t, z, a_z, a_l, f_out, nd_out, vz_out, s);
     if (D == 2 && hutch) return split_aug_t<2, true>(a, t, z, a_z, a_l, f_out, nd_out, vz_out, s);
+    if (D == 16 && hutch) return split_aug_t<16, true>(a, t, z, a_z, a_l, f_out, nd_out, vz_out, s);
     return hipErrorNotSupported;
 }
 

@@ -80,6 +80,20 @@ __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ 
     }
 }
 
+// Diagnostics: overwrite the whole LDS of every CU with a bit pattern (cnf_debug_fill_lds).  LDS keeps what the last
+// kernel on the CU left behind; the tests poison it with NaNs to prove no solve depends on that content.
+__global__ __launch_bounds__(256) void fill_lds_kernel(unsigned pattern, unsigned* __restrict__ sink) {
+    __shared__ unsigned buf[160 * 1024 / 4];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) buf[i] = pattern;
+    __syncthreads();
+    if (buf[(threadIdx.x * 97 + blockIdx.x) % (160 * 1024 / 4)] != pattern) *sink = 1u;   // keeps the stores alive
+}
+
+hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s) {
+    hipLaunchKernelGGL(fill_lds_kernel, dim3(4096), dim3(256), 0, s, pattern, sink);
+    return hipGetLastError();
+}
+
 hipError_t launch_nll_loss(const float* z, const float* dlogp, long rows, int dim, float* loss_out, float* grad_z,
                            float* grad_dlogp, hipStream_t s) {
     hipLaunchKernelGGL(nll_loss_kernel, dim3(1), dim3(kLossThreads), 0, s, z, dlogp, rows, dim, loss_out, grad_z, grad_dlogp);

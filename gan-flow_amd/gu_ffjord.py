@@ -218,7 +218,10 @@ class FusedTrainStep:
         for i, blk in enumerate(self.blocks):
             for k in (0, 1):
                 st = self._native.Stats(words[i, k])
-                st.raise_for_status()
+                try:
+                    st.raise_for_status()
+                except self._native.CnfError as err:
+                    raise self._native.CnfError("block %d, %s solve: %s (%r)" % (i, ("forward", "adjoint")[k], err, st)) from None
                 nfe[k] += st.nfe
             _inner(blk.odefunc)._num_evals.fill_(float(words[i, 0, 1] + words[i, 1, 1] + 1))
             if not self.nets[i].flat_is_current():

@@ -140,6 +140,11 @@ typedef struct CnfAdamOpts {
 int cnf_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, int32_t *state,
                   int64_t n, const CnfAdamOpts *opts, void *stream);
 
+/* Diagnostics (no counterpart in the reference): fill the LDS of every compute unit with `pattern`.  LDS keeps the
+ * previous kernel's content, so the tests poison it (NaN bit patterns) before a solve to prove that no result
+ * depends on it.  scratch_word: one uint32 of device memory (never written in practice).                    */
+int cnf_debug_fill_lds(uint32_t pattern, uint32_t *scratch_word, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

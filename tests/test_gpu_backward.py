@@ -46,7 +46,7 @@ def _oracle_aug(m, t, z, a_z, a_l, e=None):
 
 
 @pytest.mark.parametrize("case", ["fixture_uni", "fixture_multi", "rand_d1", "rand_d2", "rand_d2_ragged", "rand_d2_hutch",
-                                  "rand_d2_big"])
+                                  "rand_d2_big", "rand_d16_hutch", "rand_d16_ragged_hutch"])
 def test_eval_aug_matches_autograd(case):
     nat = _native()
     g = torch.Generator().manual_seed(17)
@@ -57,7 +57,7 @@ def test_eval_aug_matches_autograd(case):
         dim, rows = 1, 300
         z = torch.rand(rows, 1, generator=g) * (1.0 if which == "unimodal" else 76.0) + (4.5 if which == "unimodal" else 7.0)
     else:
-        dim = 1 if "d1" in case else 2
+        dim = 16 if "d16" in case else (1 if "d1" in case else 2)
         rows = 77 if "ragged" in case else (4500 if "big" in case else 256)   # > 4096 rows: one-wave-per-tile kernels
         m = oracle_random_model(dim, seed=5, divergence_fn="approximate" if hutch else "brute_force", scale=2.0)
         z = torch.randn(rows, dim, generator=g) * 1.5
@@ -100,7 +100,8 @@ def _oracle_train_grads(m, x):
 
 
 @pytest.mark.parametrize("case,rows", [("rand_d2", 2048), ("rand_d2", 100), ("rand_d1", 64), ("fixture_uni", 512), ("rand_d2_hutch", 256),
-                                       ("rand_d2", 4200), ("fixture_uni", 4100)])
+                                       ("rand_d2", 4200), ("fixture_uni", 4100), ("rand_d16_hutch", 2048),
+                                       ("rand_d16_hutch", 50)])
 def test_solve_bwd_matches_oracle_adjoint(case, rows):
     nat = _native()
     g = torch.Generator().manual_seed(23)
@@ -110,7 +111,7 @@ def test_solve_bwd_matches_oracle_adjoint(case, rows):
         dim = 1
         x = torch.rand(rows, 1, generator=g) + 4.5
     else:
-        dim = 1 if "d1" in case else 2
+        dim = 16 if "d16" in case else (1 if "d1" in case else 2)
         m = oracle_random_model(dim, seed=7, divergence_fn="approximate" if hutch else "brute_force", scale=2.0)
         x = torch.randn(rows, dim, generator=g)
     e = torch.randn(rows, dim, generator=g) if hutch else None
@@ -223,3 +224,34 @@ def test_graphed_train_step_matches_eager():
     print("graph ", ["%.4f" % v for v in lg])
     assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(le, lg))
     assert rel_err(pg, pe) < 1e-6
+
+
+@pytest.mark.parametrize("dim,hutch,rows", [(2, False, 2048), (2, False, 4500), (16, True, 512), (1, False, 300)])
+def test_solves_do_not_depend_on_stale_lds(dim, hutch, rows):
+    """LDS keeps the previous kernel's content.  Poison it with NaNs / huge values before the forward and adjoint
+    solves (both kernel families, batch-global and tile-local control): results must be bit-identical to a clean run."""
+    nat = _native()
+    g = torch.Generator().manual_seed(31)
+    m = oracle_random_model(dim, seed=9, divergence_fn="approximate" if hutch else "brute_force", scale=1.5)
+    net = nat.net_desc(dim, 64, 3, hutch)
+    params = _flat(m).to(DEV)
+    x = torch.randn(rows, dim, generator=g).to(DEV)
+    e = torch.randn(rows, dim, generator=g).to(DEV) if hutch else None
+    outs = []
+    for pattern in (0x00000000, 0x7FC00000, 0x7F7FFFFF, 0xFF800000):
+        res = []
+        for tile_rows in (0, 16):
+            opts = nat.make_opts("dopri5", 1e-5, 1e-5, tile_rows=tile_rows)
+            nat.debug_fill_lds(pattern)
+            z1, l1, s_f = nat.solve_fwd(net, params, x, None, 0.0, 0.5, opts, e)
+            res += [z1, l1, s_f[:4]]
+            if tile_rows == 0 and (dim <= 2 or rows <= 4096):
+                nat.debug_fill_lds(pattern)
+                gx, gl, gp, s_b = nat.solve_bwd(net, params, z1, l1, z1 / rows, torch.full_like(l1, 1.0 / rows), 0.0, 0.5, opts, e)
+                res += [gx, gp, s_b[:4]]
+        torch.cuda.synchronize()
+        assert all(int(r[0]) == 0 for r in res if r.dtype == torch.int32), "solver status"
+        outs.append([r.cpu() for r in res])
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)

@@ -126,3 +126,26 @@ def test_fused_train_step_two_blocks_hutchinson():
     step.check()
     print("two-block losses", ["%.3f" % v for v in losses])
     assert all(torch.isfinite(torch.tensor(losses))) and min(losses[-3:]) < losses[0]
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_train_step_d16_hutchinson_gmm(graph):
+    """BASELINE config 5 in small: d=16 Gaussian mixture, Hutchinson divergence (a fresh probe every iteration, fixed
+    within it for the forward and the adjoint solve), batch 2048.  The loss moves toward the data entropy."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gmm import GaussianMixture
+    data = GaussianMixture(16, device=DEV, sample_seed=3)
+    floor = data.entropy_estimate(50000)
+    torch.manual_seed(3)
+    model = gu_ffjord.build_model(16, divergence_fn="approximate").to(DEV).train()
+    step = gu_ffjord.FusedTrainStep(model, data.get_sample(2048), lr=1e-3, weight_decay=1e-5, graph=graph)
+    losses = [step(data.get_sample(2048)).item() for _ in range(40)]
+    nfe = step.check()
+    print("d16 losses", ["%.2f" % v for v in losses[::5]], "floor %.2f" % floor, "NFE", nfe)
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert sum(losses[-5:]) / 5 < sum(losses[:5]) / 5 - 1.0 and min(losses) > floor
+    e1 = model.chain[0].odefunc.odefunc._e
+    step(data.get_sample(2048))
+    e2 = model.chain[0].odefunc.odefunc._e
+    if not graph:
+        assert e1 is not e2 and not torch.equal(e1, e2)       # a new probe per iteration

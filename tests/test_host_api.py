@@ -114,3 +114,16 @@ def test_w_distance_matches_scipy():
     assert w_distance(a, b) == np.round(wasserstein_distance(a.numpy().squeeze(), b.numpy().squeeze()), 4)
     c = torch.randn(3000, 1, generator=g)
     assert w_distance(a, c) == np.round(wasserstein_distance(a.numpy().squeeze(), c.numpy().squeeze()), 4)
+
+
+def test_gaussian_mixture_data_config5():
+    """The synthetic d=16 mixture of BASELINE config 5: seeded, reproducible, and its log_prob is a density
+    (entropy of 8 well-separated unit Gaussians = d/2 (1 + log 2 pi) + log 8)."""
+    import math
+    from gan_flow_amd.gmm import GaussianMixture
+    a, b = GaussianMixture(16, sample_seed=5), GaussianMixture(16, sample_seed=5)
+    xa, xb = a.get_sample(4096), b.get_sample(4096)
+    assert xa.shape == (4096, 16) and torch.equal(xa, xb) and torch.equal(a.means, b.means)
+    assert not torch.equal(xa, GaussianMixture(16, sample_seed=6).get_sample(4096))
+    h = a.entropy_estimate(100000)
+    assert abs(h - (8 * (1 + math.log(2 * math.pi)) + math.log(8))) < 0.1
