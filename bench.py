@@ -39,7 +39,8 @@ def parse():
     p.add_argument("--steps", type=int, default=30)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=2048)
-    p.add_argument("--eval-rows", type=int, default=1 << 20, help="rows of the sharded log-likelihood evaluation")
+    p.add_argument("--eval-rows", type=int, default=1 << 24,
+                   help="rows of the sharded log-likelihood evaluation and of the sharded sampling (BASELINE config 3: 2^24)")
     p.add_argument("--late-steps", type=int, default=3)
     p.add_argument("--cpu-iters", type=int, default=12, help="oracle iterations timed for cpu_baseline (rank 0, N=1)")
     p.add_argument("--mode", type=str, default="fused", choices=["fused", "graph", "eager"],
@@ -208,13 +209,19 @@ def measure_roofline(ctx):
     z1, l1, _ = _native.solve_fwd(net, params, x, None, 0.0, T, opts)
     gz, gl = z1 / args.batch, torch.full_like(l1, 1.0 / args.batch)
     reps = 20
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in ev:
+    # kernel-only duration: the library records HIP events on the launch stream right around the solve kernel
+    # (cnf_debug_kernel_timing); the whole call (memset of the slabs + kernel + slab reduction) is bracketed as well
+    _native.kernel_timing(True)
+    ms = call_ms = 0.0
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         st = _native.solve_bwd(net, params, z1, l1, gz, gl, 0.0, T, opts)[3]
         b.record()
-    torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b) for a, b in ev) / reps
+        ms += _native.last_kernel_ms() / reps
+        torch.cuda.synchronize()
+        call_ms += a.elapsed_time(b) / reps
+    _native.kernel_timing(False)
     st = _native.Stats(st)
     flops = args.batch * st.nfe * 3 * F_EVAL_D2
     achieved = flops / (ms * 1e-3) / 1e12
@@ -225,7 +232,7 @@ def measure_roofline(ctx):
             traffic = json.load(fh)["hbm_bytes_per_launch"]
     return {"bound": "mfma", "kernel": "dopri5_bwd_split_kernel<2,false>", "achieved": round(achieved, 4),
             "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5),
-            "traffic": traffic, "launch_ms": round(ms, 4), "nfe": st.nfe, "evals_run": st.evals_run, "flop_per_launch": flops}
+            "traffic": traffic, "launch_ms": round(ms, 4), "call_ms": round(call_ms, 4), "nfe": st.nfe, "evals_run": st.evals_run, "flop_per_launch": flops}
 
 
 def measure_late(ctx):
@@ -305,6 +312,7 @@ def measure_eval(ctx):
             work["nfe_max"] = max(work["nfe_max"], st.nfe)
         return torch.cat(parts, 0)
 
+    sample_fn, _ = gu_ffjord.get_transforms(em)
     with torch.no_grad():
         parallel_eval.sharded_mean_log_likelihood(lp, xs[: 1 << 14])
         work["row_evals"], work["nfe_max"] = 0, 0
@@ -312,13 +320,25 @@ def measure_eval(ctx):
         t0 = time.perf_counter()
         mean_lp, rows = parallel_eval.sharded_mean_log_likelihood(lp, xs)
         ctx["barrier"]()
-    eel = ctx["max_over_ranks"](time.perf_counter() - t0)
+        eel = ctx["max_over_ranks"](time.perf_counter() - t0)
+        ll_evals = work["row_evals"]
+        # sampling half of config 3: eval_rows prior draws through sample_fn (reverse solve), samples stay sharded
+        del xs
+        ctx["barrier"]()
+        t0 = time.perf_counter()
+        smp = parallel_eval.sharded_sample(sample_fn, args.eval_rows, 1, rank, world, dev, seed=7, chunk=1 << 18)
+        ctx["barrier"]()
+        sel = ctx["max_over_ranks"](time.perf_counter() - t0)
+        smp_mean = smp.double().mean().item()
     return {"value": round(rows / eel, 1), "unit": "samples/s", "rows": rows, "scaling": "strong",
-            "mean_log_likelihood": round(mean_lp, 5), "rank0_mean_nfe": round(work["row_evals"] / max(1, n_loc), 1),
+            "mean_log_likelihood": round(mean_lp, 5), "rank0_mean_nfe": round(ll_evals / max(1, n_loc), 1),
             "rank0_max_nfe": work["nfe_max"],
-            "rank0_tflops": round(work["row_evals"] * F_EVAL_D1 / eel / 1e12, 3),
-            "workload": "log-likelihood of %d synthetic points under the trained gu_num=8 CNF (d=1 checkpoint), "
-                        "tile-local dopri5 1e-5, batch-sharded, one all-reduce of 2 x f64" % rows}
+            "rank0_tflops": round(ll_evals * F_EVAL_D1 / eel / 1e12, 3),
+            "sampling": {"value": round(args.eval_rows / sel, 1), "unit": "samples/s", "rows": args.eval_rows,
+                         "rank0_sample_mean": round(smp_mean, 4)},
+            "workload": "log-likelihood of %d synthetic points, then %d samples, under the trained gu_num=8 CNF (d=1 "
+                        "checkpoint), tile-local dopri5 1e-5, batch-sharded, one all-reduce of 2 x f64"
+                        % (rows, args.eval_rows)}
 
 
 def measure_cpu(ctx):

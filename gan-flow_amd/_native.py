@@ -38,7 +38,8 @@ STATUS_MESSAGES = {
     4: "grid-wide reduction timed out inside the solver kernel",
 }
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
-           "cnf_eval_aug", "cnf_solve_bwd", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds")
+           "cnf_eval_aug", "cnf_solve_bwd", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
+           "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms")
 
 
 def library_path():
@@ -74,6 +75,10 @@ def load_library():
     lib.cnf_nll_loss.argtypes = [P, P, I64, ctypes.c_int32, P, P, P, VP]
     lib.cnf_adam_step.restype = ctypes.c_int
     lib.cnf_adam_step.argtypes = [P, P, P, P, P, I64, ctypes.POINTER(CnfAdamOpts), VP]
+    lib.cnf_debug_kernel_timing.restype = ctypes.c_int
+    lib.cnf_debug_kernel_timing.argtypes = [ctypes.c_int]
+    lib.cnf_debug_last_kernel_ms.restype = ctypes.c_int
+    lib.cnf_debug_last_kernel_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     lib.cnf_debug_fill_lds.restype = ctypes.c_int
     lib.cnf_debug_fill_lds.argtypes = [ctypes.c_uint32, P, VP]
     _LIB = lib
@@ -278,3 +283,17 @@ def debug_fill_lds(pattern=0x7FC00000, device=None):
     with torch.cuda.device(device):
         _check(lib.cnf_debug_fill_lds(int(pattern), _ptr(word), _stream()), lib)
     return word
+
+
+def kernel_timing(enable):
+    """Diagnostics: bracket the solve kernel of every following solve call with HIP events (see last_kernel_ms)."""
+    lib = load_library()
+    _check(lib.cnf_debug_kernel_timing(1 if enable else 0), lib)
+
+
+def last_kernel_ms():
+    """Duration of the most recent solve kernel launched while kernel_timing(True) was on (waits for it)."""
+    lib = load_library()
+    ms = ctypes.c_float(0.0)
+    _check(lib.cnf_debug_last_kernel_ms(ctypes.byref(ms)), lib)
+    return float(ms.value)

@@ -24,6 +24,21 @@ hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s);
 }  // namespace cnf
 
 namespace {
+// cnf_debug_kernel_timing: events bracketing the solve kernel of the most recent solve call (process-wide, diagnostics)
+bool g_timing = false;
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+}  // namespace
+
+namespace cnf {
+void dbg_timing_begin(hipStream_t s) {
+    if (g_timing) (void)hipEventRecord(g_ev0, s);
+}
+void dbg_timing_end(hipStream_t s) {
+    if (g_timing) (void)hipEventRecord(g_ev1, s);
+}
+}  // namespace cnf
+
+namespace {
 
 thread_local std::string g_err = "";
 
@@ -266,6 +281,25 @@ int cnf_debug_fill_lds(uint32_t pattern, uint32_t* scratch_word, void* stream) {
     if (!scratch_word) return fail("cnf_debug_fill_lds: NULL pointer");
     hipError_t err = cnf::launch_fill_lds(pattern, scratch_word, (hipStream_t)stream);
     if (err != hipSuccess) return fail("cnf_debug_fill_lds: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int cnf_debug_kernel_timing(int enable) {
+    if (enable && !g_ev0) {
+        hipError_t err = hipEventCreate(&g_ev0);
+        if (err == hipSuccess) err = hipEventCreate(&g_ev1);
+        if (err != hipSuccess) return fail("cnf_debug_kernel_timing: hipEventCreate failed: %s", hipGetErrorString(err));
+    }
+    g_timing = enable != 0;
+    return 0;
+}
+
+int cnf_debug_last_kernel_ms(float* ms_out) {
+    if (!ms_out) return fail("cnf_debug_last_kernel_ms: NULL pointer");
+    if (!g_ev0) return fail("cnf_debug_last_kernel_ms: timing was never enabled");
+    hipError_t err = hipEventSynchronize(g_ev1);
+    if (err == hipSuccess) err = hipEventElapsedTime(ms_out, g_ev0, g_ev1);
+    if (err != hipSuccess) return fail("cnf_debug_last_kernel_ms: %s", hipGetErrorString(err));
     return 0;
 }
 

@@ -794,7 +794,9 @@ hipError_t launch_eval_aug(int D, bool hutch, const SolveArgs& a, float t, const
 template <int D, bool HUTCH>
 static hipError_t launch_solve_bwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRowsPerWG - 1) / kRowsPerWG);
+    dbg_timing_begin(s);
     hipLaunchKernelGGL((dopri5_bwd_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     const int P = make_layout(D, kH).total;

@@ -362,6 +362,7 @@ hipError_t launch_field(int D, bool hutch, const float* params, float t, const f
 template <int D, bool HUTCH>
 static hipError_t launch_solve_t(const SolveArgs& a, int solver, bool global, hipStream_t s) {
     const int grid = (int)((a.rows + kRowsPerWG - 1) / kRowsPerWG);
+    dbg_timing_begin(s);
     if (solver == CNF_SOLVER_RK4) {
         hipLaunchKernelGGL((rk4_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
     } else if (global) {
@@ -369,6 +370,7 @@ static hipError_t launch_solve_t(const SolveArgs& a, int solver, bool global, hi
     } else {
         hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
     }
+    dbg_timing_end(s);
     return hipGetLastError();
 }
 

@@ -32,4 +32,8 @@ hipError_t launch_field(int D, bool hutch, const float* params, float t, const f
                         float* f_out, float* nd_out, hipStream_t s);
 hipError_t launch_solve_fwd(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
 
+// diagnostics (cnf_debug_kernel_timing): when enabled, record a HIP event on `s` right before / after a solve kernel
+void dbg_timing_begin(hipStream_t s);
+void dbg_timing_end(hipStream_t s);
+
 }  // namespace cnf

@@ -1004,7 +1004,9 @@ __global__ void reduce_slab_split_kernel(const float* __restrict__ slab, int nwg
 template <int D, bool HUTCH>
 static hipError_t split_fwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
+    dbg_timing_begin(s);
     hipLaunchKernelGGL((dopri5_split_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    dbg_timing_end(s);
     return hipGetLastError();
 }
 
@@ -1019,7 +1021,9 @@ hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
 template <int D, bool HUTCH>
 static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
+    dbg_timing_begin(s);
     hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     const int P = make_layout(D, kH).total;

@@ -145,6 +145,14 @@ int cnf_adam_step(float *params, const float *grad, float *exp_avg, float *exp_a
  * depends on it.  scratch_word: one uint32 of device memory (never written in practice).                    */
 int cnf_debug_fill_lds(uint32_t pattern, uint32_t *scratch_word, void *stream);
 
+/* Diagnostics (no counterpart in the reference): while enabled, cnf_solve_fwd / cnf_solve_bwd record a HIP event on
+ * the launch stream immediately before and after their solve kernel (not the memsets, not the slab reduction);
+ * cnf_debug_last_kernel_ms waits for the second event and returns the elapsed time of the most recent solve kernel.
+ * Process-wide, one device at a time, not for use under graph capture: this is how bench.py measures the
+ * `roofline` kernel duration on the stream the kernel runs on.                                              */
+int cnf_debug_kernel_timing(int enable);
+int cnf_debug_last_kernel_ms(float *ms_out);
+
 #ifdef __cplusplus
 }
 #endif
