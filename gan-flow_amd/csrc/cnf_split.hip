@@ -358,12 +358,21 @@ struct SmallIdxS {   // parameters other than the two 64x64 matrices, canonical 
     __host__ __device__ static int canonical(int si) { return si < n0 ? si : (si < v3 ? si + kH * kH : si + 2 * kH * kH); }
 };
 
+// The seventh stage of a Dormand-Prince step is the first stage of the next one (FSAL).  Its state slopes are reused as
+// they are; its d/dtheta sum G enters the quadrature with a weight that is only known once the next step size is, so
+// it is accumulated UNWEIGHTED into a buffer of its own ("last"), promoted to "first" when the step is accepted and
+// added to the step's sums with weight wq[0] at commit time.  This removes the re-evaluation of the first stage
+// (7 -> 6 evaluations per attempt).  Needs two more copies of the small-parameter sums in LDS: d <= 2 only.
+template <int D>
+constexpr bool kFsalTheta = D <= 2;
+
 template <int D>
 struct alignas(16) SplitBwdLds {
     float wimgT[2][16][64][4];            // as BwdNetLds::wimgT
     float trB[2][kNSMaxOf<D>][kH * kRows];     // transposed layer inputs, all 64 features: [buffer][stream][feature*16 + pos(row)]
     float trA[kNW][kNSMaxOf<D>][16 * kRows];   // per wave: transposed, weighted cotangents of its own 16 features
-    float small[SmallIdxS<D>::padded];    // the step's d/dtheta of the small parameters (waves own disjoint features)
+    float small[kFsalTheta<D> ? 3 : 1][SmallIdxS<D>::padded];   // d/dtheta of the small parameters (waves own disjoint
+                                          // features): [0] the step's weighted sum, [1], [2] the FSAL buffers
     float part2[kNW][D][kRows];           // vjp_z partial sums of every wave
     float wq[8];                          // quadrature weights of the current attempt
 };
@@ -391,7 +400,7 @@ template <int D, bool HUTCH, class WS>
 __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D>& sb, WS& ws, SplitXchg<D>& xc, int lane,
                                                int wave, float t, const float (&z)[D], const float (&e)[D],
                                                const float (&az)[D], float al, float w, bool with_theta, float (&f)[D],
-                                               float& div, float (&vz)[D], BigAccS& acc) {
+                                               float& div, float (&vz)[D], BigAccS& acc, float* __restrict__ small) {
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     using SI = SmallIdxS<D>;
@@ -527,7 +536,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                     const float v = row16_allsum_s(ubar[m] * act[0][r] + Ubar[m] * act[HUTCH ? 1 : 1 + m][r]);
                     mine = (j == m) ? v : mine;
                 }
-                if (j < D) sb.small[SI::l4 + j * kH + fo + r] += w * mine;
+                if (j < D) small[SI::l4 + j * kH + fo + r] += w * mine;
             }
         }
         if (with_theta) {
@@ -538,7 +547,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 const float gg = g4[m] * (1.0f - g4[m]);
                 const float val = qq < 2 ? s4 : gb;
                 const float fac = qq == 0 ? g4[m] : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
-                if (wave == 0 && lane < 4) sb.small[SI::l4 + kH * D + qq * D + m] += w * fac * val;
+                if (wave == 0 && lane < 4) small[SI::l4 + kH * D + qq * D + m] += w * fac * val;
             }
         }
     }
@@ -584,7 +593,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 const float gg = g[r] * (1.0f - g[r]);
                 const float val = qq < 2 ? st : gt;
                 const float fac = qq == 0 ? g[r] : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
-                if (j < 4) sb.small[SI::vec(L) + qq * kH + fo + r] += w * fac * val;
+                if (j < 4) small[SI::vec(L) + qq * kH + fo + r] += w * fac * val;
             }
         }
         if (l >= 0) {
@@ -671,7 +680,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                         const float v = row16_allsum_s(fmaf(cot[0][r], z[m], tang));
                         mine = (j == m) ? v : mine;
                     }
-                    if (j < D) sb.small[(fo + r) * D + j] += w * mine;
+                    if (j < D) small[(fo + r) * D + j] += w * mine;
                 }
             }
             __syncthreads();
@@ -687,7 +696,7 @@ __device__ inline void commit_step_split(SplitBwdLds<D>& sb, const BigAccS& acc,
     const ParamLayout L = make_layout(D, kH);
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
     __syncthreads();
-    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads) slab_wg[SmallIdxS<D>::canonical(i)] += sb.small[i];
+    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads) slab_wg[SmallIdxS<D>::canonical(i)] += sb.small[0][i];
 #pragma unroll
     for (int l = 0; l < 2; ++l)
 #pragma unroll
@@ -695,6 +704,27 @@ __device__ inline void commit_step_split(SplitBwdLds<D>& sb, const BigAccS& acc,
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] += acc.gw[l][Ti][r];
+    __syncthreads();
+}
+
+// commit with the FSAL buffers: step sums + w_first * G(first stage) + w_last * G(seventh stage)
+template <int D>
+__device__ inline void commit_step_fsal(SplitBwdLds<D>& sb, const BigAccS& acc, const BigAccS& gfirst, const BigAccS& glast,
+                                        int i_first, int i_last, float w_first, float w_last,
+                                        float* __restrict__ slab_wg, int tid) {
+    const ParamLayout L = make_layout(D, kH);
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    __syncthreads();
+    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads)
+        slab_wg[SmallIdxS<D>::canonical(i)] += fmaf(w_last, sb.small[i_last][i], fmaf(w_first, sb.small[i_first][i], sb.small[0][i]));
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] +=
+                    fmaf(w_last, glast.gw[l][Ti][r], fmaf(w_first, gfirst.gw[l][Ti][r], acc.gw[l][Ti][r]));
     __syncthreads();
 }
 
@@ -723,7 +753,7 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     stage_net(net, a.params, tid);
     stage_wimgT<D>(&sb.wimgT[0][0][0][0], a.params, tid);
-    for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) sb.small[i] = 0.f;
+    for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) sb.small[0][i] = 0.f;
     __syncthreads();
     const long row = (long)blockIdx.x * kRows + j;
     const bool valid = row < a.rows;
@@ -738,7 +768,8 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     const float al = valid ? a_l[rr] : 0.f;
     BigAccS acc;
     acc.zero();
-    aug_eval_split<D, HUTCH>(net, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc);
+    aug_eval_split<D, HUTCH>(net, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc,
+                             sb.small[0]);
     if (w == 0 && lane < 16 && valid) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -764,6 +795,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     stage_net(net, a.params, tid);
     stage_wimgT<D>(&sb.wimgT[0][0][0][0], a.params, tid);
     zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid);
+    for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += kThreads) (&sb.small[0][0])[i] = 0.f;
     __syncthreads();
     const long row = (long)blockIdx.x * kRows + j;
     const bool valid = row < a.rows;
@@ -799,8 +831,12 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     int nacc = 0, nrej = 0, status = 0, nrun = 0;
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[CE];
-    BigAccS acc;
+    constexpr bool FSAL = kFsalTheta<D>;
+    BigAccS acc, gfirst, glast;   // acc: the working accumulator of aug_eval_split; gfirst / glast: see kFsalTheta
     acc.zero();
+    gfirst.zero();
+    glast.zero();
+    int i_first = 1, i_last = 2;  // which of sb.small[1], sb.small[2] holds the first / seventh stage's sums
 
     for (;;) {
         float zz[D], az[D], f[D], vz[D], div, k[C];
@@ -810,9 +846,24 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             zz[m] = yi[m];
             az[m] = yi[D + 1 + m];
         }
-        const float wst = phase == PH_STAGE ? sb.wq[stage] : 0.f;
+        // which d/dtheta sum this evaluation feeds: the step's weighted quadrature, or (FSAL) an unweighted buffer
+        const bool to_first = FSAL && phase == PH_F0;
+        const bool to_last = FSAL && phase == PH_STAGE && stage == 6;
+        const float wst = (to_first || to_last) ? 1.f : (phase == PH_STAGE ? sb.wq[stage] : 0.f);
         const bool with_theta = wst != 0.f;
-        aug_eval_split<D, HUTCH>(net, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc);
+        float* small = &sb.small[0][0];
+        BigAccS keep;
+        if (FSAL && (to_first || to_last)) {
+            small = &sb.small[to_first ? i_first : i_last][0];
+            keep = acc;
+            acc.zero();
+        }
+        aug_eval_split<D, HUTCH>(net, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc, small);
+        if (FSAL && (to_first || to_last)) {
+            if (to_first) gfirst = acc;
+            else glast = acc;
+            acc = keep;
+        }
         ++nrun;
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -894,10 +945,19 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                 const bool accept = (rz <= 1.f) && (rl <= 1.f);
                 if (accept) {
                     ++nacc;
-                    commit_step_split<D>(sb, acc, slab, tid);
+                    if (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid);
+                    else commit_step_split<D>(sb, acc, slab, tid);
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
                     for (int c = 0; c < C; ++c) y0[c] = y1[c];
+                    if (FSAL) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) ws.kst[0][c][j] = k[c];   // the seventh stage is the next step's first
+                        gfirst = glast;
+                        const int t_ = i_first;
+                        i_first = i_last;
+                        i_last = t_;
+                    }
                     tau = tau + dt;
                 } else {
                     ++nrej;
@@ -911,11 +971,14 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             if (nacc + nrej >= a.max_steps) { status = CNF_ERR_MAX_STEPS; break; }
             dtf = (float)dt;
             t0f = (float)tau;
-            stage = 0;
+            stage = FSAL ? 1 : 0;
             phase = PH_STAGE;
             acc.zero();
             __syncthreads();   // every wave is past its last read of small / wq of the previous attempt
-            for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) sb.small[i] = 0.f;
+            for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) {
+                sb.small[0][i] = 0.f;
+                if (FSAL) sb.small[i_last][i] = 0.f;
+            }
             if (tid < 7) {
                 const int s = tid;
                 float v;
