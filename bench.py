@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F_EVAL_D2 = 2 * 8448 + 2 * 2 * (8448 - 2 * 64)   # 50 176 FLOP per sample-eval (d=2, H=64^3, exact div)
 F_EVAL_D1 = 2 * 8320 + 2 * 1 * (8320 - 1 * 64)   # 33 152 (d=1 fixtures)
+F_EVAL_D2_H256 = 2 * 132096 + 2 * 2 * (132096 - 2 * 256)   # 790 528 per block (d=2, H=256^3, exact divergence)
 PEAK_FP32_MATRIX_TFLOPS = 157.3                  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 
 
@@ -46,8 +47,8 @@ def parse():
     p.add_argument("--mode", type=str, default="fused", choices=["fused", "graph", "eager"],
                    help="fused: gu_ffjord.FusedTrainStep (solves + cnf_nll_loss + cnf_adam_step, one hipGraph replay per "
                         "iteration); graph: autograd + torch.optim.Adam loop captured as one hipGraph; eager: that loop, launched eagerly")
-    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,cpu",
-                   help="comma list of the additional measurements to run: roofline, late, eval, d16, cpu ('' = none)")
+    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,wide,cpu",
+                   help="comma list of the additional measurements to run: roofline, late, eval, d16, wide, cpu ('' = none)")
     return p.parse_args()
 
 
@@ -185,6 +186,8 @@ def main():
         out["eval"] = measure_eval(ctx)
     if "d16" in extras:
         out["d16_hutchinson"] = measure_d16(ctx)
+    if "wide" in extras:
+        out["h256_forward"] = measure_wide(ctx)
     if "cpu" in extras and rank == 0 and world == 1 and args.cpu_iters > 0:
         out["cpu_baseline"] = measure_cpu(ctx)
 
@@ -281,6 +284,39 @@ def measure_d16(ctx):
             "workload": "FFJORD CNF on the synthetic d=16 8-component Gaussian mixture, B=%d, ODEnet 16-64-64-64-16, "
                         "Hutchinson divergence (Gaussian probe, fresh per iteration), dopri5 1e-5, adjoint, Adam; "
                         "seed 1+rank per GPU" % args.batch}
+
+
+def measure_wide(ctx):
+    """BASELINE config 4 (forward path): 4 stacked CNF blocks of hidden width 256, d=2, random init seed 1.  Density
+    evaluation at B=2048 with the reference's batch-global step control, and at B=65 536 with tile-local control."""
+    from gan_flow_amd import gu_ffjord
+    args, world, rank, dev = ctx["args"], ctx["world"], ctx["rank"], ctx["dev"]
+    torch.manual_seed(1)
+    model = gu_ffjord.build_model(2, dims=(256, 256, 256), num_blocks=4).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(11 + rank)
+    out = {}
+    for name, rows, tile in (("b2048_batch_global", 2048, 0), ("b65536_tile_local", 65536, 16)):
+        for b in model.chain:
+            b.tile_rows = tile
+        x = torch.randn(rows, 2, generator=g, device=dev)
+        zero = torch.zeros(rows, 1, device=dev)
+        with torch.no_grad():
+            model(x, zero)
+            reps = 5
+            evals = 0
+            ctx["barrier"]()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                model(x, zero)
+                evals += sum(b.last_stats["forward"].row_evals for b in model.chain)
+            ctx["barrier"]()
+            el = ctx["max_over_ranks"](time.perf_counter() - t0)
+        out[name] = {"rows_per_s": round(world * reps * rows / el, 1), "ms_per_pass": round(1e3 * el / reps, 3),
+                     "nfe_per_block": [b.last_stats["forward"].nfe for b in model.chain],
+                     "rank0_tflops": round(evals * F_EVAL_D2_H256 / el / 1e12, 2)}
+    out["workload"] = ("log-density pass through 4 stacked CNF blocks, ODEnet 2-256-256-256-2, exact divergence, dopri5 1e-5, "
+                       "random init seed 1; forward path only (the adjoint at this width is not built)")
+    return out
 
 
 def measure_eval(ctx):

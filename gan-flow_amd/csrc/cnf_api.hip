@@ -21,6 +21,10 @@ hipError_t launch_nll_loss(const float* z, const float* dlogp, long rows, int di
                            float* grad_dlogp, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state, long n, const CnfAdamOpts& o, hipStream_t s);
 hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s);
+// hidden width 256, forward path (cnf_wide.hip)
+hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
+                             float* f_out, float* nd_out, hipStream_t s);
+hipError_t launch_wide_solve(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
 }  // namespace cnf
 
 namespace {
@@ -54,18 +58,24 @@ int fail(const char* fmt, ...) {
 
 constexpr size_t kGranBytes = 2 * (size_t)cnf::kMaxWG * 4 * sizeof(unsigned long long);  // 16 KiB
 
+constexpr int kWideH = 256;   // cnf_wide.hip
+
+bool is_wide(const CnfNetDesc* n) { return n->hidden == kWideH; }
+
 bool supported(const CnfNetDesc* n) {
-    if (!n || n->hidden != cnf::kH || n->n_hidden != 3) return false;
+    if (!n || (n->hidden != cnf::kH && n->hidden != kWideH) || n->n_hidden != 3) return false;
     const bool hutch = n->divergence == CNF_DIV_HUTCHINSON;
     if (n->divergence != CNF_DIV_EXACT && !hutch) return false;
+    if (is_wide(n)) return (n->dim == 1 && !hutch) || n->dim == 2;
     return (n->dim == 1 && !hutch) || n->dim == 2 || (n->dim == 16 && hutch);
 }
 
 int check_net(const CnfNetDesc* n) {
     if (!n) return fail("net is NULL");
     if (!supported(n))
-        return fail("unsupported net: dim=%d hidden=%d n_hidden=%d divergence=%d (built: hidden 64 x 3; dim 1|2 exact, "
-                    "dim 2|16 Hutchinson)", n->dim, n->hidden, n->n_hidden, n->divergence);
+        return fail("unsupported net: dim=%d hidden=%d n_hidden=%d divergence=%d (built: hidden 64 x 3 with dim 1|2 exact, "
+                    "dim 2|16 Hutchinson; hidden 256 x 3 with dim 1|2 exact, dim 2 Hutchinson, forward path only)",
+                    n->dim, n->hidden, n->n_hidden, n->divergence);
     return 0;
 }
 
@@ -101,6 +111,7 @@ int64_t cnf_param_count(const CnfNetDesc* net) {
 
 size_t cnf_workspace_bytes(const CnfNetDesc* net, int64_t rows) {
     if (!supported(net) || rows <= 0) return 0;
+    if (is_wide(net)) return kGranBytes;   // forward path only: reduction granules, no gradient slabs
     const size_t P = (size_t)cnf::make_layout(net->dim, net->hidden).total;
     return kGranBytes + align16((size_t)n_slabs(net, rows) * P * sizeof(float));
 }
@@ -112,6 +123,12 @@ int cnf_eval_field(const CnfNetDesc* net, const float* params, float t, const fl
     if (rows <= 0) return fail("cnf_eval_field: rows must be positive (got %ld)", (long)rows);
     const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
     if (hutch && !e) return fail("cnf_eval_field: Hutchinson divergence needs the probe e");
+    if (is_wide(net)) {
+        if (((uintptr_t)params & 15) != 0) return fail("cnf_eval_field: params must be 16-byte aligned for hidden width 256");
+        hipError_t werr = cnf::launch_wide_field(net->dim, hutch, params, t, z, e, rows, f_out, neg_div_out, (hipStream_t)stream);
+        if (werr != hipSuccess) return fail("cnf_eval_field: launch failed: %s", hipGetErrorString(werr));
+        return 0;
+    }
     hipError_t err = cnf::launch_field(net->dim, hutch, params, t, z, e, rows, f_out, neg_div_out, (hipStream_t)stream);
     if (err != hipSuccess) return fail("cnf_eval_field: launch failed: %s", hipGetErrorString(err));
     return 0;
@@ -146,6 +163,9 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
         if (opts->tile_rows != 0 && opts->tile_rows != cnf::kRows)
             return fail("%s: tile_rows must be 0 (batch-global step control) or %d", who, cnf::kRows);
         global = opts->tile_rows == 0;
+        if (global && is_wide(net) && rows > (int64_t)cnf::kRows * cnf::kMaxWG)
+            return fail("%s: batch-global step control at hidden width 256 supports at most %d rows per solve (got %ld); "
+                        "split the batch or use tile_rows=%d", who, cnf::kRows * cnf::kMaxWG, (long)rows, cnf::kRows);
         if (global && n_wg(rows) > cnf::kMaxWG)
             return fail("%s: batch-global step control supports at most %d rows per solve (got %ld); split the batch into "
                         "chunks as the reference's evaluation does, or use tile_rows=%d", who,
@@ -187,8 +207,11 @@ int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, co
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(workspace, 0, kGranBytes, s);
     if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    if (is_wide(net) && ((uintptr_t)params & 15) != 0)
+        return fail("cnf_solve_fwd: params must be 16-byte aligned for hidden width 256");
     if (err == hipSuccess) {
-        if (opts->solver == CNF_SOLVER_DOPRI5 && global && use_split(net, rows)) err = cnf::launch_split_fwd(net->dim, hutch, a, s);
+        if (is_wide(net)) err = cnf::launch_wide_solve(net->dim, hutch, a, opts->solver, global, s);
+        else if (opts->solver == CNF_SOLVER_DOPRI5 && global && use_split(net, rows)) err = cnf::launch_split_fwd(net->dim, hutch, a, s);
         else err = cnf::launch_solve_fwd(net->dim, hutch, a, opts->solver, global, s);
     }
     if (err != hipSuccess) return fail("cnf_solve_fwd: launch failed: %s", hipGetErrorString(err));
@@ -199,6 +222,7 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
                  const float* a_logp, int64_t rows, float* f_out, float* neg_div_out, float* vjp_z_out,
                  float* vjp_params_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (check_net(net)) return 1;
+    if (is_wide(net)) return fail("cnf_eval_aug: the adjoint is not built for hidden width 256 (forward path only)");
     if (!params || !z || !a_z || !a_logp || !f_out || !neg_div_out || !vjp_z_out || !vjp_params_out || !workspace)
         return fail("cnf_eval_aug: NULL pointer");
     if (rows <= 0) return fail("cnf_eval_aug: rows must be positive (got %ld)", (long)rows);
@@ -231,6 +255,8 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
                   size_t workspace_bytes, CnfStats* stats, void* stream) {
     cnf::SolveArgs a;
     bool global;
+    if (net && supported(net) && is_wide(net))
+        return fail("cnf_solve_bwd: the adjoint is not built for hidden width 256 (forward path only)");
     if (fill_common("cnf_solve_bwd", net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
     if (!z1 || !logp1 || !grad_z1 || !grad_logp1 || !grad_x || !grad_logp0 || !grad_params)
         return fail("cnf_solve_bwd: NULL pointer");

@@ -1,0 +1,550 @@
+// cnf_wide.hip -- hidden width 256 (BASELINE config 4: stacked CNF blocks with 256-wide ConcatSquashLinear layers).
+//
+// At H = 256 a hidden layer is a real dense contraction: 256 x 256 weights = 256 KB per layer, more than the LDS
+// holds, 768 MFMAs per layer per 16-row tile.  Decomposition: ONE 16-row tile per WORKGROUP, the four waves split the
+// 16 output-feature tiles (wave w owns features 64w .. 64w+63 = 4 MFMA tiles, all streams).  Layer inputs are
+// exchanged through LDS in the C/D register layout exactly as in cnf_split.hip (16 tiles x 3 streams = 48 KB per
+// buffer, two buffers).  The WEIGHTS are not staged in LDS: with the k order of the C/D-as-B trick, the A operands
+// of the four MFMAs of a 16x16 block are W[16 To + (lane & 15)][16 Ti + 4 (lane >> 4) + 0..3] -- 16 contiguous bytes
+// of the row-major nn.Linear weight -- so every wave streams the 64 blocks of its output tiles per layer straight
+// from the parameter vector (L2-resident, identical for all workgroups) into registers with one
+// global_load_dwordx4 per block, software-prefetched one input tile ahead.  Per CU that is 256 KB per layer
+// against ~25k cycles of MFMA work per wave, i.e. ~10 B/clk of L2 bandwidth: the layer is MFMA-bound.
+// Forward path only (field evaluation, dopri5 with batch-global or tile-local control, rk4); the adjoint at this
+// width needs 2 x 256 x 256 gradient accumulators per workgroup, which do not fit in registers: not built yet.
+#include "cnf_launch.h"
+
+namespace cnf {
+
+constexpr int kWH = 256;                 // hidden width
+constexpr int kWT = kWH / 16;            // feature tiles per layer (16)
+constexpr int kWTW = kWT / kNW;          // output tiles per wave (4)
+constexpr int kWF = kWH / kNW;           // features per wave (64)
+
+template <int D>
+struct alignas(16) WideNetLds {
+    float w1[D][kWH];
+    float w4[D][kWH];
+    float vec[3][4][kWH];
+    float vec4[4][16];
+};
+
+template <int C>
+struct alignas(16) WideWaveLds {
+    float gate[3][2][kWF];   // gates of this wave's 64 features
+    float gate4[2][16];
+    float kst[7][C][kRows];
+};
+
+template <int D, int NS>
+struct alignas(16) WideXchg {
+    float xb[2][NS][kWT][64][4];
+    float part[kNW][2 * D][kRows];
+};
+
+template <int D>
+__device__ inline void wide_stage_net(WideNetLds<D>& n, const float* __restrict__ p, int tid) {
+    const ParamLayout L = make_layout(D, kWH);
+    for (int idx = tid; idx < D * kWH; idx += kThreads) {
+        const int m = idx / kWH, i = idx % kWH;
+        n.w1[m][i] = p[L.w(0) + i * D + m];
+        n.w4[m][i] = p[L.w(3) + m * kWH + i];
+    }
+    for (int idx = tid; idx < 3 * kWH; idx += kThreads) {
+        const int l = idx / kWH, i = idx % kWH;
+        n.vec[l][0][i] = p[L.b(l) + i];
+        n.vec[l][1][i] = p[L.hb(l) + i];
+        n.vec[l][2][i] = p[L.wg(l) + i];
+        n.vec[l][3][i] = p[L.bg(l) + i];
+    }
+    if (tid < 16) {
+        const bool in = tid < D;
+        n.vec4[0][tid] = in ? p[L.b(3) + tid] : 0.f;
+        n.vec4[1][tid] = in ? p[L.hb(3) + tid] : 0.f;
+        n.vec4[2][tid] = in ? p[L.wg(3) + tid] : 0.f;
+        n.vec4[3][tid] = in ? p[L.bg(3) + tid] : 0.f;
+    }
+}
+
+__device__ __forceinline__ float wsum4(float a, float b, float c, float d) { return ((a + b) + c) + d; }
+
+// ---- forward dynamics -----------------------------------------------------------------------------------------
+template <int D, bool HUTCH, class WS>
+__device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, WideXchg<D, (HUTCH ? 1 : D) + 1>& xc,
+                                               const float* __restrict__ params, int lane, int wave, float t,
+                                               const float (&z)[D], const float (&e)[D], float (&f)[D], float& div) {
+    constexpr int NT = HUTCH ? 1 : D;
+    constexpr int NS = NT + 1;
+    const int q = lane >> 4, j = lane & 15;
+    // gates of this wave's features, one per lane
+    {
+        const int fi = kWF * wave + lane;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const float g = sigmoid_f(fmaf(n.vec[l][2][fi], t, n.vec[l][3][fi]));
+            ws.gate[l][0][lane] = g;
+            ws.gate[l][1][lane] = fmaf(g, n.vec[l][0][fi], n.vec[l][1][fi] * t);
+        }
+        if (lane < 16) {
+            const float g = sigmoid_f(fmaf(n.vec4[2][lane], t, n.vec4[3][lane]));
+            ws.gate4[0][lane] = g;
+            ws.gate4[1][lane] = fmaf(g, n.vec4[0][lane], n.vec4[1][lane] * t);
+        }
+        wave_lds_fence();
+    }
+    f32x4 act[kWTW][NS];
+    // layer 1 (K = d): vector ALU
+#pragma unroll
+    for (int T = 0; T < kWTW; ++T) {
+        const int lo = 16 * T + 4 * q, fo = kWF * wave + lo;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[0][0][lo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[0][1][lo]);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
+        f32x4 wcol[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            wcol[m] = *reinterpret_cast<const f32x4*>(&n.w1[m][fo]);
+            a += wcol[m] * z[m];
+            if (HUTCH) au += wcol[m] * e[m];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
+            const float dg = (1.0f - x * x) * g[r];
+            act[T][0][r] = x;
+            if (HUTCH) {
+                act[T][1][r] = dg * au[r];
+            } else {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) act[T][1 + m][r] = dg * wcol[m][r];
+            }
+        }
+    }
+    // layers 2, 3: 256 x 256 on the matrix cores, weights streamed from the (L2-resident) parameter vector
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int T = 0; T < kWTW; ++T)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][kWTW * wave + T][lane][0]) = act[T][s];
+        // row 64 wave + 16 T + j of W, columns 16 Ti + 4 q .. + 3
+        const float* wrow = params + make_layout(D, kWH).w(1 + l) + (size_t)(kWF * wave + j) * kWH + 4 * q;
+        f32x4 wnext[kWTW];
+#pragma unroll
+        for (int T = 0; T < kWTW; ++T) wnext[T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH);   // input tile 0, issued before the barrier
+        __syncthreads();
+        f32x4 acc[kWTW][NS];
+#pragma unroll
+        for (int T = 0; T < kWTW; ++T)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[T][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int Ti = 0; Ti < kWT; ++Ti) {
+            f32x4 wcur[kWTW];
+#pragma unroll
+            for (int T = 0; T < kWTW; ++T) wcur[T] = wnext[T];
+            const int Tn = Ti + 1 < kWT ? Ti + 1 : Ti;
+#pragma unroll
+            for (int T = 0; T < kWTW; ++T) wnext[T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * Tn);
+            f32x4 in[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
+#pragma unroll
+            for (int T = 0; T < kWTW; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma16(wcur[T][r], in[s][r], acc[T][s]);
+        }
+#pragma unroll
+        for (int T = 0; T < kWTW; ++T) {
+            const int lo = 16 * T + 4 * q;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][lo]);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][lo]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = tanh_f(fmaf(g[r], acc[T][0][r], c[r]));
+                const float dg = (1.0f - x * x) * g[r];
+                act[T][0][r] = x;
+#pragma unroll
+                for (int s = 1; s < NS; ++s) act[T][s][r] = dg * acc[T][s][r];
+            }
+        }
+    }
+    // layer 4 (N = d): this wave's 64 features, then across waves through LDS
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        float pf = 0.f, pd = 0.f;
+#pragma unroll
+        for (int T = 0; T < kWTW; ++T) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&n.w4[m][kWF * wave + 16 * T + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf = fmaf(w4[r], act[T][0][r], pf);
+                pd = fmaf(w4[r], act[T][HUTCH ? 1 : 1 + m][r], pd);
+            }
+        }
+        pf = xq_sum(pf);
+        pd = xq_sum(pd);
+        if (q == 0) {
+            xc.part[wave][m][j] = pf;
+            xc.part[wave][D + m][j] = pd;
+        }
+    }
+    __syncthreads();
+    div = 0.f;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        const float g4 = ws.gate4[0][m];
+        const float u4 = wsum4(xc.part[0][m][j], xc.part[1][m][j], xc.part[2][m][j], xc.part[3][m][j]);
+        const float U4 = wsum4(xc.part[0][D + m][j], xc.part[1][D + m][j], xc.part[2][D + m][j], xc.part[3][D + m][j]);
+        f[m] = fmaf(g4, u4, ws.gate4[1][m]);
+        const float dm = g4 * U4;
+        div += HUTCH ? dm * e[m] : dm;
+    }
+}
+
+// ---- one evaluation (cnf_eval_field) ------------------------------------------------------------------------------
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void wide_field_kernel(const float* __restrict__ params,
+                                                              float t, const float* __restrict__ z, const float* __restrict__ e,
+                                                              long rows, float* __restrict__ f_out, float* __restrict__ nd_out) {
+    constexpr int NS = (HUTCH ? 1 : D) + 1;
+    __shared__ WideNetLds<D> net;
+    __shared__ WideWaveLds<D + 1> wl[kNW];
+    __shared__ WideXchg<D, NS> xc;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    wide_stage_net(net, params, tid);
+    __syncthreads();
+    const long row = (long)blockIdx.x * kRows + j;
+    const long rr = row < rows ? row : rows - 1;
+    float zz[D], ee[D], f[D], div;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        zz[m] = z[rr * D + m];
+        ee[m] = HUTCH ? e[rr * D + m] : 0.f;
+    }
+    field_fwd_wide<D, HUTCH>(net, wl[w], xc, params, lane, w, t, zz, ee, f, div);
+    if (w == 0 && lane < 16 && row < rows) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) f_out[row * D + m] = f[m];
+        nd_out[row] = -div;
+    }
+}
+
+// ---- fixed-grid RK4 (3/8 rule), as rk4_kernel in cnf_fwd.hip ---------------------------------------------------
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void wide_rk4_kernel(SolveArgs a) {
+    constexpr int NS = (HUTCH ? 1 : D) + 1;
+    constexpr int C = D + 1;
+    __shared__ WideNetLds<D> net;
+    __shared__ WideWaveLds<C> wl[kNW];
+    __shared__ WideXchg<D, NS> xc;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    wide_stage_net(net, a.params, tid);
+    __syncthreads();
+    const long base = (long)blockIdx.x * kRows;
+    const long row = base + j;
+    const long rr = row < a.rows ? row : a.rows - 1;
+    float y[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+    }
+    y[D] = a.logp0 ? a.logp0[rr] : 0.f;
+    const float sgn = a.t1 >= a.t0 ? 1.f : -1.f;
+    const float tau0 = sgn * a.t0, tau1 = sgn * a.t1;
+    for (int step = 0; step < a.n_grid; ++step) {
+        float ta = a.n_grid == 1 ? tau0 : __fadd_rn(__fmul_rn((float)step, a.step_size), tau0);
+        float tb = (step + 1 == a.n_grid) ? tau1 : __fadd_rn(__fmul_rn((float)(step + 1), a.step_size), tau0);
+        const float dt = tb - ta;
+        float k1[C], k2[C], k3[C], yi[C];
+        float ti = ta;
+#pragma unroll
+        for (int c = 0; c < C; ++c) yi[c] = y[c];
+        for (int st = 0; st < 4; ++st) {
+            float zz[D], f[D], div, k[C];
+#pragma unroll
+            for (int m = 0; m < D; ++m) zz[m] = yi[m];
+            field_fwd_wide<D, HUTCH>(net, wl[w], xc, a.params, lane, w, sgn * ti, zz, ee, f, div);
+#pragma unroll
+            for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
+            k[D] = -sgn * div;
+            if (st == 0) {
+                ti = ta + dt / 3;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k1[c] = k[c]; yi[c] = y[c] + dt * k[c] / 3; }
+            } else if (st == 1) {
+                ti = ta + dt * 2 / 3;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k2[c] = k[c]; yi[c] = y[c] + dt * (k1[c] / -3 + k[c]); }
+            } else if (st == 2) {
+                ti = ta + dt;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k3[c] = k[c]; yi[c] = y[c] + dt * (k1[c] - k2[c] + k[c]); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + (k1[c] + 3 * k2[c] + 3 * k3[c] + k[c]) * (dt / 8);
+            }
+        }
+    }
+    if (w == 0 && lane < 16 && row < a.rows) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) a.z_out[row * D + m] = y[m];
+        a.logp_out[row] = y[D];
+    }
+    if (tid == 0) {
+        atomicMax(&a.stats->nfe, 4 * a.n_grid);
+        atomicMax(&a.stats->n_accepted, a.n_grid);
+        atomicMax(&a.stats->evals_run, 4 * a.n_grid);
+        long nrow = a.rows - base < kRows ? a.rows - base : kRows;
+        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(nrow * 4 * a.n_grid));
+    }
+}
+
+// ---- dopri5: the controller of dopri5_split_kernel (cnf_split.hip); GLOBAL = false: this tile is the control group
+template <int D, bool HUTCH, bool GLOBAL>
+__global__ __launch_bounds__(kThreads) void wide_dopri5_kernel(SolveArgs a) {
+    constexpr int NS = (HUTCH ? 1 : D) + 1;
+    constexpr int C = D + 1;
+    __shared__ WideNetLds<D> net;
+    __shared__ WideWaveLds<C> wl[kNW];
+    __shared__ WideXchg<D, NS> xc;
+    __shared__ RedLds red;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    if (tid == 0) red.status = 0;
+    wide_stage_net(net, a.params, tid);
+    zero_slopes(wl, kNW, tid);
+    __syncthreads();
+    const long base = (long)blockIdx.x * kRows;
+    const long row = base + j;
+    // GLOBAL: every wave carries the same 16 rows, wave 0 reports them to the grid-wide sum.  Tile-local: every wave
+    // reduces its own (identical) copy, so all four reach the same decision without a barrier.
+    const bool counted = row < a.rows && lane < 16 && (GLOBAL ? w == 0 : true);
+    const long rr = row < a.rows ? row : a.rows - 1;
+    WideWaveLds<C>& ws = wl[w];
+
+    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    const double nl = GLOBAL ? (double)a.rows : (double)(a.rows - base < kRows ? a.rows - base : kRows);
+    const double nz = nl * D;
+
+    float y0[C], y1[C], yi[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y0[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+    }
+    y0[D] = a.logp0 ? a.logp0[rr] : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) yi[c] = y0[c];
+
+    const float sgn = a.t1 >= a.t0 ? 1.f : -1.f;
+    const double tau_end = (double)(sgn * a.t1);
+    double tau = (double)(sgn * a.t0);
+    double dt = 0.0;
+    float dtf = 0.f, t0f = (float)tau, ti = t0f;
+    const float rtol = a.rtol, atol = a.atol;
+
+    enum { PH_F0 = 0, PH_F1 = 1, PH_STAGE = 2 };
+    int phase = PH_F0, stage = 0;
+    int nfe = 0, nacc = 0, nrej = 0, status = 0;
+    float h0 = 0.f, d1z = 0.f, d1l = 0.f;
+    float sc[C];
+
+    auto reduce = [&](double (&S)[4]) -> bool {
+        if (GLOBAL) return wg_allreduce4(gs, red, S, w, lane);
+        wave_allreduce4(S);
+        return true;
+    };
+
+    for (;;) {
+        float zz[D], f[D], div, k[C];
+        bool restart = false;
+#pragma unroll
+        for (int m = 0; m < D; ++m) zz[m] = yi[m];
+        field_fwd_wide<D, HUTCH>(net, ws, xc, a.params, lane, w, sgn * ti, zz, ee, f, div);
+        ++nfe;
+#pragma unroll
+        for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
+        k[D] = -sgn * div;
+
+        if (phase == PH_F0) {
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                ws.kst[0][c][j] = k[c];
+                sc[c] = atol + fabsf(y0[c]) * rtol;
+                const float u = y0[c] / sc[c], v = k[c] / sc[c];
+                if (counted) {
+                    S[c < D ? 0 : 1] += (double)u * u;
+                    S[c < D ? 2 : 3] += (double)v * v;
+                }
+            }
+            if (!reduce(S)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
+            d1z = (float)sqrt(S[2] / nz);
+            d1l = (float)sqrt(S[3] / nl);
+            if (pymax(d0z, d0l) < 1e-5f || pymax(d1z, d1l) < 1e-5f) {
+                h0 = 1e-6f;
+            } else {
+                h0 = 0.01f * pymax(d0z / d1z, d0l / d1l);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) yi[c] = y0[c] + h0 * k[c];
+            ti = t0f + h0;
+            phase = PH_F1;
+            continue;
+        }
+        if (phase == PH_F1) {
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float u = (k[c] - ws.kst[0][c][j]) / sc[c];
+                if (counted) S[c < D ? 0 : 1] += (double)u * u;
+            }
+            if (!reduce(S)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
+            float h1;
+            if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
+                h1 = fmaxf(1e-6f, h0 * 1e-3f);
+            } else {
+                h1 = powf(0.01f / pymax(pymax(pymax(d1z, d1l), d2z), d2l), 0.2f);
+            }
+            dt = (double)fminf(100.f * h0, h1);
+            restart = true;
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) ws.kst[stage][c][j] = k[c];
+            if (stage < 6) {
+                ++stage;
+            } else {
+                double S[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    y1[c] = yi[c];
+                    float err = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c]));
+                    const float u = err / tol;
+                    if (counted) {
+                        S[c < D ? 0 : 1] += (double)u * u;
+                        if (!isfinite(y0[c])) S[2] += 1.0;
+                    }
+                }
+                if (!reduce(S)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
+                const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
+                const bool accept = (rz <= 1.f) && (rl <= 1.f);
+                if (accept) {
+                    ++nacc;
+                    if (!(tau_end > tau + dt)) break;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        y0[c] = y1[c];
+                        ws.kst[0][c][j] = k[c];
+                    }
+                    tau = tau + dt;
+                } else {
+                    ++nrej;
+                }
+                dt = next_step_size(dt, pymax(rz, rl));
+                restart = true;
+            }
+        }
+        if (restart) {
+            if (!(tau + dt > tau)) { status = CNF_ERR_DT_UNDERFLOW; break; }
+            if (nacc + nrej >= a.max_steps) { status = CNF_ERR_MAX_STEPS; break; }
+            dtf = (float)dt;
+            t0f = (float)tau;
+            stage = 1;
+            phase = PH_STAGE;
+        }
+        float alpha_, bc_[6];
+        stage_coeffs(stage, alpha_, bc_);
+        ti = t0f + alpha_ * dtf;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) acc += (dtf * bc_[s]) * ws.kst[s][c][j];
+            yi[c] = y0[c] + acc;
+        }
+    }
+
+    if (status == 0) {
+        const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+        const float x = (te - ta) / (tb - ta);
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float mid = 0.f;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * ws.kst[s][c][j];
+            mid = y0[c] + mid;
+            const float f0 = ws.kst[0][c][j], f1 = ws.kst[6][c][j], u = y0[c], v = y1[c];
+            const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
+            const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
+            const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
+            const float cd = dtf * f0;
+            y1[c] = ca * x4 + cb * x3 + cc * x2 + cd * x + u;
+        }
+        if (w == 0 && lane < 16 && row < a.rows) {
+#pragma unroll
+            for (int m = 0; m < D; ++m) a.z_out[row * D + m] = y1[m];
+            a.logp_out[row] = y1[D];
+        }
+    }
+    if (tid == 0 && (!GLOBAL || blockIdx.x == 0 || status != 0)) {
+        if (status) atomicMax(&a.stats->status, status);
+        atomicMax(&a.stats->nfe, nfe);
+        atomicMax(&a.stats->n_accepted, nacc);
+        atomicMax(&a.stats->n_rejected, nrej);
+        atomicMax(&a.stats->evals_run, nfe);
+        if (GLOBAL) a.stats->last_dt = (float)dt;
+        const long nrow = GLOBAL ? a.rows : (a.rows - base < kRows ? a.rows - base : kRows);
+        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(nrow * (long)nfe));
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------
+template <int D, bool HUTCH>
+static hipError_t wide_field_t(const float* params, float t, const float* z, const float* e, long rows,
+                               float* f_out, float* nd_out, hipStream_t s) {
+    const int grid = (int)((rows + kRows - 1) / kRows);
+    hipLaunchKernelGGL((wide_field_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, params, t, z, e, rows, f_out, nd_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, const float* z,
+                             const float* e, long rows, float* f_out, float* nd_out, hipStream_t s) {
+    if (D == 1 && !hutch) return wide_field_t<1, false>(params, t, z, e, rows, f_out, nd_out, s);
+    if (D == 2 && !hutch) return wide_field_t<2, false>(params, t, z, e, rows, f_out, nd_out, s);
+    if (D == 2 && hutch) return wide_field_t<2, true>(params, t, z, e, rows, f_out, nd_out, s);
+    return hipErrorNotSupported;
+}
+
+template <int D, bool HUTCH>
+static hipError_t wide_solve_t(const SolveArgs& a, int solver, bool global, hipStream_t s) {
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    dbg_timing_begin(s);
+    if (solver == CNF_SOLVER_RK4) {
+        hipLaunchKernelGGL((wide_rk4_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    } else if (global) {
+        hipLaunchKernelGGL((wide_dopri5_kernel<D, HUTCH, true>), dim3(grid), dim3(kThreads), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((wide_dopri5_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
+    }
+    dbg_timing_end(s);
+    return hipGetLastError();
+}
+
+hipError_t launch_wide_solve(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s) {
+    if (D == 1 && !hutch) return wide_solve_t<1, false>(a, solver, global, s);
+    if (D == 2 && !hutch) return wide_solve_t<2, false>(a, solver, global, s);
+    if (D == 2 && hutch) return wide_solve_t<2, true>(a, solver, global, s);
+    return hipErrorNotSupported;
+}
+
+}  // namespace cnf

@@ -39,7 +39,7 @@ extern "C" {
  * Replaces the Python object graph ODEfunc(ODEnet(...)).            */
 typedef struct CnfNetDesc {
     int32_t dim;        /* data dimension d: 1, 2 or 16                                          */
-    int32_t hidden;     /* hidden width: 64                                                      */
+    int32_t hidden;     /* hidden width: 64, or 256 (forward entry points only, dim 1 | 2)       */
     int32_t n_hidden;   /* number of hidden layers: 3                                            */
     int32_t divergence; /* 0 = brute force (exact trace, `divergence_bf`), 1 = Hutchinson
                            (`divergence_approx`, probe `e` fixed for the whole solve)           */
