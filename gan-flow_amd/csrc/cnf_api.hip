@@ -25,6 +25,11 @@ hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s);
 hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
                              float* f_out, float* nd_out, hipStream_t s);
 hipError_t launch_wide_solve(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
+// hidden width 256, adjoint (cnf_wide_bwd.hip); ws_floats = workspace past the granules
+size_t wide_bwd_workspace_floats(int D, long rows);
+hipError_t launch_wide_bwd(int D, bool hutch, const SolveArgs& a, float* ws_floats, hipStream_t s);
+hipError_t launch_wide_aug(int D, bool hutch, const SolveArgs& a, float* ws_floats, float t, const float* z, const float* a_z,
+                           const float* a_l, float* f_out, float* nd_out, float* vz_out, hipStream_t s);
 }  // namespace cnf
 
 namespace {
@@ -111,7 +116,11 @@ int64_t cnf_param_count(const CnfNetDesc* net) {
 
 size_t cnf_workspace_bytes(const CnfNetDesc* net, int64_t rows) {
     if (!supported(net) || rows <= 0) return 0;
-    if (is_wide(net)) return kGranBytes;   // forward path only: reduction granules, no gradient slabs
+    if (is_wide(net)) {
+        // forward: granules only.  Adjoint (rows <= 4096): transposed matrices + 8 gradient slots per 16-row tile.
+        if (rows > (int64_t)cnf::kRows * cnf::kMaxWG) return kGranBytes;
+        return kGranBytes + cnf::wide_bwd_workspace_floats(net->dim, rows) * sizeof(float);
+    }
     const size_t P = (size_t)cnf::make_layout(net->dim, net->hidden).total;
     return kGranBytes + align16((size_t)n_slabs(net, rows) * P * sizeof(float));
 }
@@ -222,7 +231,6 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
                  const float* a_logp, int64_t rows, float* f_out, float* neg_div_out, float* vjp_z_out,
                  float* vjp_params_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (check_net(net)) return 1;
-    if (is_wide(net)) return fail("cnf_eval_aug: the adjoint is not built for hidden width 256 (forward path only)");
     if (!params || !z || !a_z || !a_logp || !f_out || !neg_div_out || !vjp_z_out || !vjp_params_out || !workspace)
         return fail("cnf_eval_aug: NULL pointer");
     if (rows <= 0) return fail("cnf_eval_aug: rows must be positive (got %ld)", (long)rows);
@@ -240,6 +248,15 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
     a.slab = (float*)((char*)workspace + kGranBytes);
     a.grad_params = vjp_params_out;
     hipStream_t s = (hipStream_t)stream;
+    if (is_wide(net)) {
+        if (rows > (int64_t)cnf::kRows * cnf::kMaxWG) return fail("cnf_eval_aug: at most %d rows at hidden width 256", cnf::kRows * cnf::kMaxWG);
+        if (((uintptr_t)params & 15) != 0 || ((uintptr_t)workspace & 15) != 0)
+            return fail("cnf_eval_aug: params and workspace must be 16-byte aligned for hidden width 256");
+        hipError_t werr = cnf::launch_wide_aug(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), t, z, a_z, a_logp,
+                                               f_out, neg_div_out, vjp_z_out, s);
+        if (werr != hipSuccess) return fail("cnf_eval_aug: launch failed: %s", hipGetErrorString(werr));
+        return 0;
+    }
     hipError_t err = hipMemsetAsync(workspace, 0, need, s);   // granules + per-workgroup gradient slabs
     if (err == hipSuccess) {
         if (use_split(net, rows)) err = cnf::launch_split_aug(net->dim, hutch, a, t, z, a_z, a_logp, f_out, neg_div_out, vjp_z_out, s);
@@ -255,8 +272,9 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
                   size_t workspace_bytes, CnfStats* stats, void* stream) {
     cnf::SolveArgs a;
     bool global;
-    if (net && supported(net) && is_wide(net))
-        return fail("cnf_solve_bwd: the adjoint is not built for hidden width 256 (forward path only)");
+    if (net && supported(net) && is_wide(net) && rows > (int64_t)cnf::kRows * cnf::kMaxWG)
+        return fail("cnf_solve_bwd: the adjoint at hidden width 256 supports at most %d rows per call (got %ld)",
+                    cnf::kRows * cnf::kMaxWG, (long)rows);
     if (fill_common("cnf_solve_bwd", net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
     if (!z1 || !logp1 || !grad_z1 || !grad_logp1 || !grad_x || !grad_logp0 || !grad_params)
         return fail("cnf_solve_bwd: NULL pointer");
@@ -274,6 +292,14 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     a.grad_logp0 = grad_logp0;
     a.grad_params = grad_params;
     hipStream_t s = (hipStream_t)stream;
+    if (is_wide(net)) {
+        if (((uintptr_t)params & 15) != 0) return fail("cnf_solve_bwd: params must be 16-byte aligned for hidden width 256");
+        hipError_t werr = hipMemsetAsync(workspace, 0, kGranBytes, s);   // the gradient slots are written before they are read
+        if (werr == hipSuccess) werr = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        if (werr == hipSuccess) werr = cnf::launch_wide_bwd(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), s);
+        if (werr != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(werr));
+        return 0;
+    }
     hipError_t err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // granules + gradient slabs
     if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
     if (err == hipSuccess) err = use_split(net, rows) ? cnf::launch_split_bwd(net->dim, hutch, a, s) : cnf::launch_solve_bwd(net->dim, hutch, a, s);

@@ -134,7 +134,7 @@ def test_wide_dopri5_tile_local_equals_oracle_per_tile():
 
 def test_wide_stacked_blocks_module_api_and_limits():
     """BASELINE config 4 shape: 4 CNF blocks of width 256 through the reference's module API (density and sampling
-    directions), against the oracle; training entry points say clearly that the adjoint is not built at this width."""
+    directions), against the oracle; batch-global control beyond 4096 rows is refused with a clear message."""
     from gan_flow_amd import gu_ffjord, _native as nat
     mo = _model(2, False, seed=6, scale=1.5, blocks=4)
     mo.eval()
@@ -150,9 +150,114 @@ def test_wide_stacked_blocks_module_api_and_limits():
     print("wide 4 blocks: z %.1e dlogp %.1e round trip %.1e" % (rel_err(z, z_ref), rel_err(dl, dl_ref), (s.cpu() - x).abs().max().item()))
     assert rel_err(z, z_ref) < 2e-4 and rel_err(dl, dl_ref) < 2e-4
     assert rel_err(s, s_ref) < 2e-4 and (s.cpu() - x).abs().max() < 1e-3
-    mp.train()
-    with pytest.raises(nat.CnfError, match="not built for hidden width 256"):
-        gu_ffjord.compute_loss(mp, x.to(DEV)).backward()
     net = nat.net_desc(2, 256, 3, False)
     with pytest.raises(nat.CnfError, match="at most 4096 rows"):
         nat.solve_fwd(net, _flat(mo).to(DEV), torch.zeros(5000, 2, device=DEV), None, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5))
+
+
+def _oracle_aug(m, t, z, a_z, a_l, e=None):
+    fn = _fn(m)
+    fn.before_odeint(e=e)
+    params = tuple(fn.diffeq.parameters())
+    with torch.enable_grad():
+        tt = torch.tensor(t, requires_grad=True)
+        zz = z.clone().requires_grad_(True)
+        ll = torch.zeros(z.shape[0], 1, requires_grad=True)
+        f, nd = fn(tt, (zz, ll))
+        grads = torch.autograd.grad((f, nd), (zz,) + params, (-a_z, -a_l), allow_unused=True)
+    vp = torch.cat([torch.zeros_like(p).reshape(-1) if g is None else g.reshape(-1) for g, p in zip(grads[1:], params)])
+    return f.detach(), nd.detach(), grads[0], vp
+
+
+@pytest.mark.parametrize("dim,hutch,rows", [(2, False, 256), (2, False, 77), (1, False, 100), (2, True, 130)])
+def test_wide_eval_aug_matches_autograd(dim, hutch, rows):
+    """One evaluation of the adjoint's augmented dynamics at width 256: f, -div, the z-VJP and the theta-VJP (every
+    parameter block separately) against autograd of the oracle."""
+    nat = _native()
+    m = _model(dim, hutch, seed=5, scale=2.0)
+    g = torch.Generator().manual_seed(17)
+    z = torch.randn(rows, dim, generator=g) * 1.5
+    a_z = torch.randn(rows, dim, generator=g)
+    a_l = torch.randn(rows, 1, generator=g)
+    e = torch.randn(rows, dim, generator=g) if hutch else None
+    net = nat.net_desc(dim, 256, 3, hutch)
+    params = _flat(m).to(DEV)
+    for t in (0.0, 0.31):
+        f_ref, nd_ref, vz_ref, vp_ref = _oracle_aug(m, t, z, a_z, a_l, e)
+        f, nd, vz, vp = nat.eval_aug(net, params, t, z.to(DEV), a_z.to(DEV), a_l.to(DEV), None if e is None else e.to(DEV))
+        torch.cuda.synchronize()
+        errs = (rel_err(f, f_ref), rel_err(nd, nd_ref), rel_err(vz, vz_ref), rel_err(vp, vp_ref))
+        print("wide aug d=%d hutch=%s t=%.2f: f %.1e -div %.1e vjp_z %.1e vjp_theta %.1e" % ((dim, hutch, t) + errs))
+        assert errs[0] < 1e-5 and errs[1] < 2e-5 and errs[2] < 2e-5 and errs[3] < 2e-5
+        off = 0
+        for name, p in _fn(m).diffeq.named_parameters():
+            k = p.numel()
+            blk, ref = vp[off:off + k].cpu(), vp_ref[off:off + k]
+            err = (blk - ref).abs().max().item()
+            bar = 5e-5 * max(ref.abs().max().item(), 1e-3 * vp_ref.abs().max().item())
+            assert err <= bar, (name, err, bar)
+            off += k
+
+
+@pytest.mark.parametrize("dim,hutch,rows", [(2, False, 2048), (2, False, 100), (1, False, 64), (2, True, 256)])
+def test_wide_solve_bwd_matches_oracle_adjoint(dim, hutch, rows):
+    """Adjoint solve at width 256 against the oracle's odeint_adjoint: same step counts, gradients within 2e-4."""
+    nat = _native()
+    g = torch.Generator().manual_seed(23)
+    m = _model(dim, hutch, seed=7, scale=2.0)
+    x = torch.randn(rows, dim, generator=g)
+    e = torch.randn(rows, dim, generator=g) if hutch else None
+    fn = _fn(m)
+    if hutch:
+        orig = fn.before_odeint
+        fn.before_odeint = lambda e_=None: orig(e=e)
+    m.zero_grad()
+    xx = x.clone().requires_grad_(True)
+    z_o, dl_o = m(xx, torch.zeros(rows, 1))
+    loss = -(oracle.standard_normal_logprob(z_o).sum(1, keepdim=True) - dl_o).mean()
+    loss.backward()
+    gp_ref = torch.cat([p.grad.reshape(-1) for p in fn.diffeq.parameters()])
+    st_ref = m.chain[0].stats
+    T = float(m.chain[0].sqrt_end_time.detach() ** 2)
+    net = nat.net_desc(dim, 256, 3, hutch)
+    params = _flat(m).to(DEV)
+    opts = nat.make_opts("dopri5", 1e-5, 1e-5)
+    ed = None if e is None else e.to(DEV)
+    z1, l1, s_f = nat.solve_fwd(net, params, x.to(DEV), None, 0.0, T, opts, ed)
+    gx, gl0, gp, s_b = nat.solve_bwd(net, params, z1, l1, z1 / rows, torch.full((rows, 1), 1.0 / rows, device=DEV), 0.0, T, opts, ed)
+    torch.cuda.synchronize()
+    s_f, s_b = nat.Stats(s_f), nat.Stats(s_b)
+    s_f.raise_for_status()
+    s_b.raise_for_status()
+    bo = st_ref["backward"]
+    e_gx, e_gp = rel_err(gx, xx.grad), rel_err(gp, gp_ref)
+    print("wide bwd d=%d rows=%d: steps hip %d+%d oracle %d+%d evals %d | grad_x %.2e grad_theta %.2e"
+          % (dim, rows, s_b.n_accepted, s_b.n_rejected, bo["n_accepted"], bo["n_rejected"], s_b.evals_run, e_gx, e_gp))
+    assert (s_b.n_accepted, s_b.n_rejected) == (bo["n_accepted"], bo["n_rejected"])
+    assert s_b.evals_run == s_b.nfe == 2 + 6 * (s_b.n_accepted + s_b.n_rejected)
+    assert torch.equal(gl0.cpu(), torch.full((rows, 1), 1.0 / rows))
+    assert e_gx < 2e-4 and e_gp < 2e-4
+    off = 0
+    for name, p in fn.diffeq.named_parameters():
+        k = p.numel()
+        blk, ref = gp[off:off + k].cpu(), gp_ref[off:off + k]
+        err = (blk - ref).abs().max().item()
+        bar = 2e-3 * max(ref.abs().max().item(), 1e-3 * gp_ref.abs().max().item())   # a wholly wrong block is O(1) off
+        assert err <= bar, (name, err, bar)
+        off += k
+
+
+def test_wide_fused_training_four_blocks():
+    """BASELINE config 4 as a training run in small: 4 stacked blocks of width 256 on gu_num=8 data, FusedTrainStep
+    (forward solves, loss, adjoint solves chained through the blocks, Adam): the loss goes down."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    data = make_gu(8, seed=4)
+    batches = [data.get_sample(2048).to(DEV) for _ in range(10)]
+    torch.manual_seed(2)
+    model = gu_ffjord.build_model(2, dims=H, num_blocks=4).to(DEV).train()
+    step = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=False)
+    losses = [step(x).item() for x in batches]
+    nfe = step.check()
+    print("wide 4-block training losses", ["%.2f" % v for v in losses], "NFE", nfe)
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
