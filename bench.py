@@ -187,7 +187,7 @@ def main():
     if "d16" in extras:
         out["d16_hutchinson"] = measure_d16(ctx)
     if "wide" in extras:
-        out["h256_forward"] = measure_wide(ctx)
+        out["h256_4blocks"] = measure_wide(ctx)
     if "cpu" in extras and rank == 0 and world == 1 and args.cpu_iters > 0:
         out["cpu_baseline"] = measure_cpu(ctx)
 
@@ -314,8 +314,27 @@ def measure_wide(ctx):
         out[name] = {"rows_per_s": round(world * reps * rows / el, 1), "ms_per_pass": round(1e3 * el / reps, 3),
                      "nfe_per_block": [b.last_stats["forward"].nfe for b in model.chain],
                      "rank0_tflops": round(evals * F_EVAL_D2_H256 / el / 1e12, 2)}
-    out["workload"] = ("log-density pass through 4 stacked CNF blocks, ODEnet 2-256-256-256-2, exact divergence, dopri5 1e-5, "
-                       "random init seed 1; forward path only (the adjoint at this width is not built)")
+    # training iteration of the same model (FusedTrainStep: 4 forward solves, loss, 4 adjoint solves, 4 Adam updates)
+    from gan_flow_amd.gu import make_gu
+    for b in model.chain:
+        b.tile_rows = 0
+    model.train()
+    data = make_gu(8, device="cpu", seed=1 + rank, extend_dim=True)
+    n_it = max(3, args.steps // 3)
+    xs = [data.get_sample(args.batch).to(dev) for _ in range(2 + n_it)]
+    step = gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True, warmup_batches=xs[:2])
+    ctx["barrier"]()
+    t0 = time.perf_counter()
+    for x in xs[2:]:
+        step(x)
+    ctx["barrier"]()
+    el = ctx["max_over_ranks"](time.perf_counter() - t0)
+    nfe_f, nfe_b = step.check()
+    flops = args.batch * (nfe_f + 3 * nfe_b) * F_EVAL_D2_H256
+    out["train_b%d" % args.batch] = {"value": round(world * n_it / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / n_it, 3),
+                                     "nfe_forward": nfe_f, "nfe_backward": nfe_b, "rank0_tflops": round(flops * n_it / el / 1e12, 2)}
+    out["workload"] = ("4 stacked CNF blocks, ODEnet 2-256-256-256-2, exact divergence, dopri5 1e-5, random init seed 1: "
+                       "log-density passes, and training iterations on gu_num=8 batches")
     return out
 
 

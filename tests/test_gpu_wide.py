@@ -261,3 +261,31 @@ def test_wide_fused_training_four_blocks():
     nfe = step.check()
     print("wide 4-block training losses", ["%.2f" % v for v in losses], "NFE", nfe)
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+
+
+def test_wide_solves_do_not_depend_on_stale_lds():
+    """As tests/test_gpu_backward.py::test_solves_do_not_depend_on_stale_lds, for the width-256 kernels."""
+    nat = _native()
+    m = _model(2, False, seed=9)
+    net = nat.net_desc(2, 256, 3, False)
+    params = _flat(m).to(DEV)
+    rows = 600
+    x = torch.randn(rows, 2, generator=torch.Generator().manual_seed(31)).to(DEV)
+    outs = []
+    for pattern in (0x00000000, 0x7FC00000, 0xFF800000):
+        res = []
+        for tile_rows in (0, 16):
+            opts = nat.make_opts("dopri5", 1e-5, 1e-5, tile_rows=tile_rows)
+            nat.debug_fill_lds(pattern)
+            z1, l1, s_f = nat.solve_fwd(net, params, x, None, 0.0, 0.5, opts)
+            res += [z1, l1, s_f[:4]]
+            if tile_rows == 0:
+                nat.debug_fill_lds(pattern)
+                gx, gl, gp, s_b = nat.solve_bwd(net, params, z1, l1, z1 / rows, torch.full_like(l1, 1.0 / rows), 0.0, 0.5, opts)
+                res += [gx, gp, s_b[:4]]
+        torch.cuda.synchronize()
+        assert all(int(r[0]) == 0 for r in res if r.dtype == torch.int32), "solver status"
+        outs.append([r.cpu() for r in res])
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
