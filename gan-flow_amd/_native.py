@@ -43,7 +43,8 @@ EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval
 
 
 def library_path():
-    return os.path.join(_HERE, "libcnf_hip.so")
+    # CNF_HIP_LIB: another build of the same library (kernel timing experiments, tools/build_variants.sh)
+    return os.environ.get("CNF_HIP_LIB") or os.path.join(_HERE, "libcnf_hip.so")
 
 
 def load_library():

@@ -395,19 +395,68 @@ struct BigAccS {
     }
 };
 
+// ---- cross-row reductions for the small-parameter gradients -----------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sums of 8 values (a[0..3], b[0..3]) over the 16 rows of a tile (the 16 lanes of a DPP row), "transposed": every
+// exchange step halves the number of values a lane carries instead of reducing each value separately.  On return lane
+// j holds the two totals of index r* = j & 3:  ta = sum_rows a[r*],  tb = sum_rows b[r*]  (11 DPP adds + 12 selects
+// against 64 DPP adds for eight separate butterflies).  b0 = j & 1, b1 = j & 2.
+__device__ __forceinline__ void reduce8(const float (&a)[4], const float (&b)[4], bool b0, bool b1, float& ta, float& tb) {
+    const float a0 = (b0 ? a[1] : a[0]) + dpp_mov<0xB1>(b0 ? a[0] : a[1]);   // quad_perm [1,0,3,2]: rows j ^ 1
+    const float a1 = (b0 ? a[3] : a[2]) + dpp_mov<0xB1>(b0 ? a[2] : a[3]);
+    const float c0 = (b0 ? b[1] : b[0]) + dpp_mov<0xB1>(b0 ? b[0] : b[1]);
+    const float c1 = (b0 ? b[3] : b[2]) + dpp_mov<0xB1>(b0 ? b[2] : b[3]);
+    float aa = (b1 ? a1 : a0) + dpp_mov<0x4E>(b1 ? a0 : a1);                 // quad_perm [2,3,0,1]: rows j ^ 2
+    float cc = (b1 ? c1 : c0) + dpp_mov<0x4E>(b1 ? c0 : c1);
+    aa += dpp_mov<0x124>(aa);                                                // row_ror:4, row_ror:8: the lanes with equal j & 3
+    cc += dpp_mov<0x124>(cc);
+    aa += dpp_mov<0x128>(aa);
+    cc += dpp_mov<0x128>(cc);
+    ta = aa;
+    tb = cc;
+}
+
+// fire-and-forget LDS accumulate (ds_add_f32): every address has ONE owner lane per evaluation and a wave's LDS
+// operations complete in order, so the sums are deterministic
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// timing experiments only (tools/build_variants.sh): drop parts of the d/dtheta work to see what they cost
+#ifdef CNF_EXP_NO_SMALL
+constexpr bool kExpSmall = false;
+#else
+constexpr bool kExpSmall = true;
+#endif
+#ifdef CNF_EXP_NO_DW
+constexpr bool kExpDw = false;
+#else
+constexpr bool kExpDw = true;
+#endif
+
 // one augmented evaluation; same mathematics as aug_eval (cnf_bwd.hip), each wave on its own feature tile
 template <int D, bool HUTCH, class WS>
 __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D>& sb, WS& ws, SplitXchg<D>& xc, int lane,
                                                int wave, float t, const float (&z)[D], const float (&e)[D],
                                                const float (&az)[D], float al, float w, bool with_theta, float (&f)[D],
-                                               float& div, float (&vz)[D], BigAccS& acc, float* __restrict__ small) {
+                                               float& div, float (&vz)[D], BigAccS& acc, int small_base) {
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     using SI = SmallIdxS<D>;
+    float* const small = &sb.small[0][0] + small_base;   // an LDS address the compiler can see (no flat atomics)
     const int q = lane >> 4, j = lane & 15, qq = j & 3;
     const int fo = 16 * wave + 4 * q;
     const int pos = (j & 3) * 4 + (j >> 2);
     gates_into(n, ws, lane, t);
+    // after reduce8 lane j owns index r* = j & 3 and parameter kind j >> 2 (bias, hyper-bias, gate weight, gate bias):
+    // factor = k0 * g + k1 * t + gg * (k2 * t + k3) as arithmetic on lane masks (nested selects compile to branches)
+    const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0;
+    const int kind = j >> 2;
+    const float km0 = kind == 0 ? 1.f : 0.f, km1t = kind == 1 ? t : 0.f, km23 = kind == 2 ? t : (kind == 3 ? 1.f : 0.f);
 
     // ------------------------------------------------------------------ forward with saves (own tile)
     f32x4 xs[3], ub[3], U[2][NT], act[NS];
@@ -529,14 +578,19 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
             }
             cot[0][r] = xb;
             if (HUTCH) cot[1][r] = Xh;
-            if (with_theta) {
-                float mine = 0.f;
+        }
+        if (with_theta && kExpSmall) {
+            // d/dW4[m][feature] = sum_rows (ubar_m x + Ubar_m X_m): two output rows m per reduce8
 #pragma unroll
-                for (int m = 0; m < D; ++m) {
-                    const float v = row16_allsum_s(ubar[m] * act[0][r] + Ubar[m] * act[HUTCH ? 1 : 1 + m][r]);
-                    mine = (j == m) ? v : mine;
+            for (int m = 0; m < D; m += 2) {
+                float va[4], vb[4], ta, tb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    va[r] = ubar[m] * act[0][r] + Ubar[m] * act[HUTCH ? 1 : 1 + m][r];
+                    vb[r] = m + 1 < D ? ubar[m + 1 < D ? m + 1 : m] * act[0][r] + Ubar[m + 1 < D ? m + 1 : m] * act[HUTCH ? 1 : 1 + (m + 1 < D ? m + 1 : m)][r] : 0.f;
                 }
-                if (j < D) small[SI::l4 + j * kH + fo + r] += w * mine;
+                reduce8(va, vb, b0, b1, ta, tb);
+                if (kind < 2 && m + kind < D) lds_add(&small[SI::l4 + (m + kind) * kH + fo + qq], w * (kind == 0 ? ta : tb));
             }
         }
         if (with_theta) {
@@ -547,10 +601,28 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 const float gg = g4[m] * (1.0f - g4[m]);
                 const float val = qq < 2 ? s4 : gb;
                 const float fac = qq == 0 ? g4[m] : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
-                if (wave == 0 && lane < 4) small[SI::l4 + kH * D + qq * D + m] += w * fac * val;
+                if (wave == 0 && lane < 4) lds_add(&small[SI::l4 + kH * D + qq * D + m], w * fac * val);
             }
         }
     }
+
+    // dW[16*wave + i'][:] += sum_rows (w ubar)[i'][row] * x_in[:][row] of hidden layer lc (K = the 16 rows).  Nothing on
+    // the evaluation's critical path depends on these 96 MFMAs, so they are issued one layer LATE, next to the
+    // reductions and gate arithmetic of the following layer: matrix pipe and vector ALU overlap.
+    auto issue_dw = [&](int lc) {
+        const int buf = 1 - lc;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.trA[wave][s][j * kRows + 4 * q]);
+            f32x4 b4[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) b4[T] = *reinterpret_cast<const f32x4*>(&sb.trB[buf][s][(16 * T + j) * kRows + 4 * q]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int Ti = 0; Ti < 4; ++Ti) acc.gw[lc][Ti] = mfma16(a4[ks], b4[Ti][ks], acc.gw[lc][Ti]);
+        }
+    };
 
 #pragma unroll
     for (int l = 1; l >= -1; --l) {
@@ -586,22 +658,23 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
             cot[0][r] = g[r] * pre;
         }
         if (with_theta) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float st = row16_allsum_s(s1[r]);
-                const float gt = row16_allsum_s(s2[r]);
-                const float gg = g[r] * (1.0f - g[r]);
-                const float val = qq < 2 ? st : gt;
-                const float fac = qq == 0 ? g[r] : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
-                if (j < 4) small[SI::vec(L) + qq * kH + fo + r] += w * fac * val;
-            }
+            if (kExpDw && l < 1) issue_dw(l + 1);   // the previous layer's outer products, next to this vector work
+        }
+        if (with_theta && kExpSmall) {
+            // every lane ends up owning one (feature fo + r*, kind) entry of this layer's four vectors: no branch, no idle lane
+            float st, gt;
+            reduce8(s1, s2, b0, b1, st, gt);
+            const float gs = b1 ? (b0 ? g[3] : g[2]) : (b0 ? g[1] : g[0]);
+            const float gg = gs * (1.0f - gs);
+            const float fac = fmaf(gg, km23, fmaf(km0, gs, km1t));
+            lds_add(&small[SI::vec(L) + kind * kH + fo + qq], w * fac * (kind < 2 ? st : gt));
         }
         if (l >= 0) {
             const int lc = l < 0 ? 0 : l;
             const int buf = 1 - lc;   // layer 3 publishes through buffer 0, layer 2 through buffer 1
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
-            if (with_theta) {
+            if (with_theta && kExpDw) {
                 const f32x4 gi = *reinterpret_cast<const f32x4*>(&ws.gate[L - 1][0][fo]);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -630,20 +703,6 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 }
             }
             __syncthreads();
-            if (with_theta) {
-                // dW[16*wave + i'][:] += sum_rows (w ubar)[i'][row] * x_in[:][row]   (K = the 16 rows)
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.trA[wave][s][j * kRows + 4 * q]);
-                    f32x4 b4[4];
-#pragma unroll
-                    for (int T = 0; T < 4; ++T) b4[T] = *reinterpret_cast<const f32x4*>(&sb.trB[buf][s][(16 * T + j) * kRows + 4 * q]);
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int Ti = 0; Ti < 4; ++Ti) acc.gw[lc][Ti] = mfma16(a4[ks], b4[Ti][ks], acc.gw[lc][Ti]);
-                }
-            }
             // cotangent of this layer's input, own input-feature tile: (W^T ubar)[16*wave ..]
             f32x4 o4[NS];
 #pragma unroll
@@ -670,17 +729,19 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 pz = xq_sum(pz);
                 if (q == 0) sb.part2[wave][m][j] = pz;
             }
-            if (with_theta) {
+            if (with_theta && kExpSmall) {
+                // d/dW1[feature][m] = sum_rows (cot z_m + tangent cotangent_m): two input columns m per reduce8
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float mine = 0.f;
+                for (int m = 0; m < D; m += 2) {
+                    const int m1 = m + 1 < D ? m + 1 : m;
+                    float va[4], vb[4], ta, tb;
 #pragma unroll
-                    for (int m = 0; m < D; ++m) {
-                        const float tang = HUTCH ? cot[1][r] * e[m] : cot[1 + (HUTCH ? 0 : m)][r];
-                        const float v = row16_allsum_s(fmaf(cot[0][r], z[m], tang));
-                        mine = (j == m) ? v : mine;
+                    for (int r = 0; r < 4; ++r) {
+                        va[r] = fmaf(cot[0][r], z[m], HUTCH ? cot[1][r] * e[m] : cot[1 + (HUTCH ? 0 : m)][r]);
+                        vb[r] = m + 1 < D ? fmaf(cot[0][r], z[m1], HUTCH ? cot[1][r] * e[m1] : cot[1 + (HUTCH ? 0 : m1)][r]) : 0.f;
                     }
-                    if (j < D) small[(fo + r) * D + j] += w * mine;
+                    reduce8(va, vb, b0, b1, ta, tb);
+                    if (kind < 2 && m + kind < D) lds_add(&small[(fo + qq) * D + m + kind], w * (kind == 0 ? ta : tb));
                 }
             }
             __syncthreads();
@@ -768,8 +829,7 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     const float al = valid ? a_l[rr] : 0.f;
     BigAccS acc;
     acc.zero();
-    aug_eval_split<D, HUTCH>(net, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc,
-                             sb.small[0]);
+    aug_eval_split<D, HUTCH>(net, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc, 0);
     if (w == 0 && lane < 16 && valid) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -851,10 +911,10 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         const bool to_last = FSAL && phase == PH_STAGE && stage == 6;
         const float wst = (to_first || to_last) ? 1.f : (phase == PH_STAGE ? sb.wq[stage] : 0.f);
         const bool with_theta = wst != 0.f;
-        float* small = &sb.small[0][0];
+        int small = 0;
         BigAccS keep;
         if (FSAL && (to_first || to_last)) {
-            small = &sb.small[to_first ? i_first : i_last][0];
+            small = (to_first ? i_first : i_last) * SmallIdxS<D>::padded;
             keep = acc;
             acc.zero();
         }
