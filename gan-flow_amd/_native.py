@@ -21,7 +21,8 @@ class CnfNetDesc(ctypes.Structure):
 
 class CnfSolverOpts(ctypes.Structure):
     _fields_ = [("solver", ctypes.c_int32), ("rtol", ctypes.c_float), ("atol", ctypes.c_float),
-                ("step_size", ctypes.c_float), ("tile_rows", ctypes.c_int32), ("max_steps", ctypes.c_int32)]
+                ("step_size", ctypes.c_float), ("tile_rows", ctypes.c_int32), ("max_steps", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
 
 
 class CnfAdamOpts(ctypes.Structure):
@@ -125,6 +126,18 @@ def _workspace(lib, net, rows, device):
     return ws
 
 
+def workspace_bytes(net, rows):
+    return int(load_library().cnf_workspace_bytes(ctypes.byref(net), rows))
+
+
+def _own_workspace(lib, net, rows, ws):
+    """A caller-owned workspace (uint8 tensor on the device), e.g. the zero-initialised one FLAG_CLEAN calls share."""
+    need = int(lib.cnf_workspace_bytes(ctypes.byref(net), rows))
+    if not (torch.is_tensor(ws) and ws.is_cuda and ws.dtype == torch.uint8 and ws.is_contiguous() and ws.numel() >= need):
+        raise CnfError("workspace must be a contiguous uint8 tensor of at least %d bytes on the HIP device" % need)
+    return ws
+
+
 def net_desc(dim, hidden, n_hidden, hutchinson):
     return CnfNetDesc(int(dim), int(hidden), int(n_hidden), DIV_HUTCHINSON if hutchinson else DIV_EXACT)
 
@@ -156,16 +169,20 @@ class Stats:
                 % (self.status, self.nfe, self.n_accepted, self.n_rejected, self.last_dt, self.evals_run, self.row_evals))
 
 
-def make_opts(solver="dopri5", rtol=1e-5, atol=1e-5, step_size=None, tile_rows=0, max_steps=0):
+FLAG_CLEAN = 1   # CNF_FLAG_CLEAN, include/cnf_hip.h
+
+
+def make_opts(solver="dopri5", rtol=1e-5, atol=1e-5, step_size=None, tile_rows=0, max_steps=0, flags=0):
     if solver not in SOLVER_IDS:
         raise CnfError("solver %r is not built into the HIP path (have: %s)" % (solver, ", ".join(SOLVER_IDS)))
-    return CnfSolverOpts(SOLVER_IDS[solver], float(rtol), float(atol), float(step_size or 0.0), int(tile_rows), int(max_steps))
+    return CnfSolverOpts(SOLVER_IDS[solver], float(rtol), float(atol), float(step_size or 0.0), int(tile_rows), int(max_steps),
+                         int(flags))
 
 
 def _stats_block(stats, device):
     """The 32-byte CnfStats block a solve writes: a fresh one, or the caller's (8 contiguous int32 on `device`)."""
     if stats is None:
-        return torch.empty(8, dtype=torch.int32, device=device)
+        return torch.empty(8, dtype=torch.int32, device=device)   # the call zeroes it (no FLAG_CLEAN without a caller's block)
     if not (stats.is_cuda and stats.dtype == torch.int32 and stats.numel() == 8 and stats.is_contiguous()):
         raise CnfError("stats must be 8 contiguous int32 words on the HIP device")
     return stats
@@ -186,7 +203,7 @@ def eval_field(net, params, t, z, e=None):
     return f, nd
 
 
-def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None):
+def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None, workspace=None):
     """State (z, logp) at t1 of the CNF ODE started from (x, logp0) at t0.  Returns (z, logp, stats_words)."""
     lib = load_library()
     x = _dev(x, "x")
@@ -198,7 +215,7 @@ def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None):
     logp = torch.empty(rows, 1, dtype=torch.float32, device=x.device)
     stats = _stats_block(stats, x.device)
     with torch.cuda.device(x.device):
-        ws = _workspace(lib, net, rows, x.device)
+        ws = _workspace(lib, net, rows, x.device) if workspace is None else _own_workspace(lib, net, rows, workspace)
         _check(lib.cnf_solve_fwd(ctypes.byref(net), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows, float(t0), float(t1),
                                  ctypes.byref(opts), _ptr(z), _ptr(logp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
     return z, logp, stats
@@ -224,7 +241,7 @@ def eval_aug(net, params, t, z, a_z, a_logp, e=None):
     return f, nd, vz, vp
 
 
-def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None, stats=None):
+def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None, stats=None, workspace=None):
     """Adjoint pass for the interval [t0, t1]: returns (grad_x, grad_logp0, grad_params, stats_words)."""
     lib = load_library()
     z1 = _dev(z1, "z1")
@@ -239,7 +256,7 @@ def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None,
     gp = torch.empty_like(params)
     stats = _stats_block(stats, z1.device)
     with torch.cuda.device(z1.device):
-        ws = _workspace(lib, net, rows, z1.device)
+        ws = _workspace(lib, net, rows, z1.device) if workspace is None else _own_workspace(lib, net, rows, workspace)
         _check(lib.cnf_solve_bwd(ctypes.byref(net), _ptr(params), _ptr(z1), _ptr(logp1), _ptr(e), _ptr(grad_z1),
                                  _ptr(grad_logp1), rows, float(t0), float(t1), ctypes.byref(opts), _ptr(gx), _ptr(gl),
                                  _ptr(gp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)

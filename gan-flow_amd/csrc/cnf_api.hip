@@ -61,7 +61,7 @@ int fail(const char* fmt, ...) {
     return 1;
 }
 
-constexpr size_t kGranBytes = 2 * (size_t)cnf::kMaxWG * 4 * sizeof(unsigned long long);  // 16 KiB
+constexpr size_t kGranBytes = 2 * (size_t)cnf::kMaxWG * 4 * sizeof(unsigned long long) + 64;  // 16 KiB of granules + the ticket word
 
 constexpr int kWideH = 256;   // cnf_wide.hip
 
@@ -214,8 +214,14 @@ int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, co
     a.z_out = z_out;
     a.logp_out = logp_out;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t err = hipMemsetAsync(workspace, 0, kGranBytes, s);
-    if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    // CNF_FLAG_CLEAN: batch-global dopri5 kernels that clean up after themselves (cnf_split.hip, cnf_wide.hip)
+    const bool clean = (opts->flags & CNF_FLAG_CLEAN) && opts->solver == CNF_SOLVER_DOPRI5 && global &&
+                       (is_wide(net) || use_split(net, rows));
+    hipError_t err = hipSuccess;
+    if (!clean) {
+        err = hipMemsetAsync(workspace, 0, kGranBytes, s);
+        if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    }
     if (is_wide(net) && ((uintptr_t)params & 15) != 0)
         return fail("cnf_solve_fwd: params must be 16-byte aligned for hidden width 256");
     if (err == hipSuccess) {
@@ -294,14 +300,26 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     hipStream_t s = (hipStream_t)stream;
     if (is_wide(net)) {
         if (((uintptr_t)params & 15) != 0) return fail("cnf_solve_bwd: params must be 16-byte aligned for hidden width 256");
-        hipError_t werr = hipMemsetAsync(workspace, 0, kGranBytes, s);   // the gradient slots are written before they are read
-        if (werr == hipSuccess) werr = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        hipError_t werr = hipSuccess;
+        if (!(opts->flags & CNF_FLAG_CLEAN)) {
+            werr = hipMemsetAsync(workspace, 0, kGranBytes, s);   // the gradient slots are written before they are read
+            if (werr == hipSuccess) werr = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        }
         if (werr == hipSuccess) werr = cnf::launch_wide_bwd(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), s);
         if (werr != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(werr));
         return 0;
     }
-    hipError_t err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // granules + gradient slabs
-    if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    hipError_t err = hipSuccess;
+    if ((opts->flags & CNF_FLAG_CLEAN) && use_split(net, rows)) {
+        // nothing to clear: granules and status are clean by contract, the slabs are stored (not accumulated) by the
+        // first accepted step
+    } else if (use_split(net, rows)) {
+        err = hipMemsetAsync(workspace, 0, kGranBytes, s);
+        if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    } else {
+        err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // granules + gradient slabs
+        if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    }
     if (err == hipSuccess) err = use_split(net, rows) ? cnf::launch_split_bwd(net->dim, hutch, a, s) : cnf::launch_solve_bwd(net->dim, hutch, a, s);
     if (err != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(err));
     return 0;

@@ -108,6 +108,7 @@ struct alignas(16) RedLds {
     double part[kNW][4];
     double tot[4];
     int status;
+    int last;   // grid_cleanup: this workgroup took the last ticket
 };
 
 template <int D>
@@ -347,7 +348,11 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
     if (w == 0) {
         double s = 0.0;
         if (lane < 4) s = red.part[0][lane] + red.part[1][lane] + red.part[2][lane] + red.part[3][lane];
+#ifdef CNF_EXP_NO_GRIDSYNC
+        if (false) {
+#else
         if (gs.nwg > 1) {
+#endif
             gs.epoch += 1;
             unsigned long long* bank = gs.gran + (size_t)(gs.epoch & 1u) * (size_t)(gs.nwg * 4);
             if (lane < 4) {
@@ -357,16 +362,26 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
             const int ng = gs.nwg * 4;
             double acc = 0.0;
             bool done = false;
+            // every lane polls its granules (g = lane, lane + 64, ...) with ALL loads of a sweep in flight at once: a
+            // sweep then costs one L2 round trip instead of one per granule
+            constexpr int kPerLane = kMaxWG * 4 / 64;
             for (unsigned spin = 0; spin < kSpinLimit; ++spin) {
+                unsigned long long x[kPerLane];
+#pragma unroll
+                for (int k = 0; k < kPerLane; ++k) {
+                    const int g = lane + 64 * k;
+                    x[k] = g < ng ? __hip_atomic_load(bank + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : ((unsigned long long)gs.epoch << 32);
+                }
                 bool ok = true;
                 acc = 0.0;
-                for (int g = lane; g < ng; g += 64) {
-                    const unsigned long long x = __hip_atomic_load(bank + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok &= (unsigned)(x >> 32) == gs.epoch;
-                    acc += (double)__uint_as_float((unsigned)x);
+#pragma unroll
+                for (int k = 0; k < kPerLane; ++k) {
+                    ok &= (unsigned)(x[k] >> 32) == gs.epoch;
+                    acc += (double)__uint_as_float((unsigned)x[k]);   // padding entries carry +0.0f
                 }
                 if (__all(ok)) { done = true; break; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
             if (!done && lane == 0) red.status = CNF_ERR_SYNC_TIMEOUT;
             acc += __shfl_xor(acc, 4);
@@ -383,6 +398,41 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = red.tot[i];
     return red.status == 0;
+}
+
+// End of a batch-global kernel: leave the granules as the next launch needs them (all zero) without a memset node.
+// Every workgroup takes a ticket after its last reduction; the one that takes the last ticket knows all the others
+// are done reading, clears both banks and resets the ticket (the word right after the banks).  All threads call it.
+constexpr int kGranWords = 2 * kMaxWG * 4;   // 8-byte granules in the two banks; the ticket is granule kGranWords
+__device__ inline void grid_cleanup(GridSync& gs, RedLds& red, int tid) {
+    if (gs.nwg <= 1) return;
+    unsigned* ticket = reinterpret_cast<unsigned*>(gs.gran + kGranWords);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        red.last = prev == (unsigned)gs.nwg - 1u;
+    }
+    __syncthreads();
+    if (red.last) {
+        for (int i = tid; i < 2 * gs.nwg * 4; i += kThreads) gs.gran[i] = 0ull;
+        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Solver statistics of a batch-global solve: workgroup 0 stores the counters (no atomics, so the block need not be
+// zeroed before the launch); the status is the one sticky word: any workgroup that failed raises it with atomicMax.
+__device__ inline void write_stats_global(CnfStats* st, int status, int nfe, int nacc, int nrej, int nrun, float last_dt,
+                                          long rows, int tid) {
+    if (tid != 0) return;
+    if (status) atomicMax(&st->status, status);
+    if (blockIdx.x == 0) {
+        st->nfe = nfe;
+        st->n_accepted = nacc;
+        st->n_rejected = nrej;
+        st->last_dt = last_dt;
+        st->evals_run = nrun;
+        st->row_evals = (int64_t)rows * nrun;
+    }
 }
 
 // tile-local variant: the 16 rows of this wave are the whole control group

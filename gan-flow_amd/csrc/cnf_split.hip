@@ -332,15 +332,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
             a.logp_out[row] = y1[D];
         }
     }
-    if (tid == 0 && (blockIdx.x == 0 || status != 0)) {
-        if (status) atomicMax(&a.stats->status, status);
-        atomicMax(&a.stats->nfe, nfe);
-        atomicMax(&a.stats->n_accepted, nacc);
-        atomicMax(&a.stats->n_rejected, nrej);
-        atomicMax(&a.stats->evals_run, nfe);
-        a.stats->last_dt = (float)dt;
-        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(a.rows * (long)nfe));
-    }
+    grid_cleanup(gs, red, tid);
+    write_stats_global(a.stats, status, nfe, nacc, nrej, nfe, (float)dt, a.rows, tid);
 }
 
 // ============================================================================================================
@@ -753,18 +746,25 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
 }
 
 template <int D>
-__device__ inline void commit_step_split(SplitBwdLds<D>& sb, const BigAccS& acc, float* __restrict__ slab_wg, int tid) {
+__device__ inline void commit_step_split(SplitBwdLds<D>& sb, const BigAccS& acc, float* __restrict__ slab_wg, int tid,
+                                         bool first = false) {
     const ParamLayout L = make_layout(D, kH);
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
     __syncthreads();
-    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads) slab_wg[SmallIdxS<D>::canonical(i)] += sb.small[0][i];
+    // first: the slab has not been written yet (and need not have been zeroed): store instead of accumulate
+    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads) {
+        float* dst = &slab_wg[SmallIdxS<D>::canonical(i)];
+        *dst = (first ? 0.f : *dst) + sb.small[0][i];
+    }
 #pragma unroll
     for (int l = 0; l < 2; ++l)
 #pragma unroll
         for (int Ti = 0; Ti < 4; ++Ti)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] += acc.gw[l][Ti][r];
+            for (int r = 0; r < 4; ++r) {
+                float* dst = &slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j];
+                *dst = (first ? 0.f : *dst) + acc.gw[l][Ti][r];
+            }
     __syncthreads();
 }
 
@@ -772,20 +772,24 @@ __device__ inline void commit_step_split(SplitBwdLds<D>& sb, const BigAccS& acc,
 template <int D>
 __device__ inline void commit_step_fsal(SplitBwdLds<D>& sb, const BigAccS& acc, const BigAccS& gfirst, const BigAccS& glast,
                                         int i_first, int i_last, float w_first, float w_last,
-                                        float* __restrict__ slab_wg, int tid) {
+                                        float* __restrict__ slab_wg, int tid, bool first) {
     const ParamLayout L = make_layout(D, kH);
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
     __syncthreads();
-    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads)
-        slab_wg[SmallIdxS<D>::canonical(i)] += fmaf(w_last, sb.small[i_last][i], fmaf(w_first, sb.small[i_first][i], sb.small[0][i]));
+    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads) {
+        float* dst = &slab_wg[SmallIdxS<D>::canonical(i)];
+        *dst = (first ? 0.f : *dst) + fmaf(w_last, sb.small[i_last][i], fmaf(w_first, sb.small[i_first][i], sb.small[0][i]));
+    }
 #pragma unroll
     for (int l = 0; l < 2; ++l)
 #pragma unroll
         for (int Ti = 0; Ti < 4; ++Ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] +=
-                    fmaf(w_last, glast.gw[l][Ti][r], fmaf(w_first, gfirst.gw[l][Ti][r], acc.gw[l][Ti][r]));
+            {
+                float* dst = &slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j];
+                *dst = (first ? 0.f : *dst) + fmaf(w_last, glast.gw[l][Ti][r], fmaf(w_first, gfirst.gw[l][Ti][r], acc.gw[l][Ti][r]));
+            }
     __syncthreads();
 }
 
@@ -1005,8 +1009,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                 const bool accept = (rz <= 1.f) && (rl <= 1.f);
                 if (accept) {
                     ++nacc;
-                    if (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid);
-                    else commit_step_split<D>(sb, acc, slab, tid);
+                    if (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid, nacc == 1);
+                    else commit_step_split<D>(sb, acc, slab, tid, nacc == 1);
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
                     for (int c = 0; c < C; ++c) y0[c] = y1[c];
@@ -1097,15 +1101,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         }
         if (counted) a.grad_logp0[row] = al;
     }
-    if (tid == 0 && (blockIdx.x == 0 || status != 0)) {
-        if (status) atomicMax(&a.stats->status, status);
-        atomicMax(&a.stats->nfe, 2 + 6 * (nacc + nrej));
-        atomicMax(&a.stats->n_accepted, nacc);
-        atomicMax(&a.stats->n_rejected, nrej);
-        atomicMax(&a.stats->evals_run, nrun);
-        a.stats->last_dt = (float)dt;
-        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(a.rows * (long)nrun));
-    }
+    grid_cleanup(gs, red, tid);
+    write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------

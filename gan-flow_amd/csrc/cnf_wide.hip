@@ -444,7 +444,10 @@ __global__ __launch_bounds__(kThreads) void wide_dopri5_kernel(SolveArgs a) {
             a.logp_out[row] = y1[D];
         }
     }
-    if (tid == 0 && (!GLOBAL || blockIdx.x == 0 || status != 0)) {
+    if (GLOBAL) {
+        grid_cleanup(gs, red, tid);
+        write_stats_global(a.stats, status, nfe, nacc, nrej, nfe, (float)dt, a.rows, tid);
+    } else if (tid == 0) {
         if (status) atomicMax(&a.stats->status, status);
         atomicMax(&a.stats->nfe, nfe);
         atomicMax(&a.stats->n_accepted, nacc);

@@ -745,21 +745,13 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
         }
         if (counted) a.grad_logp0[row] = al;
     }
-    if (tid == 0 && (blockIdx.x == 0 || status != 0)) {
-        if (status) atomicMax(&a.stats->status, status);
-        atomicMax(&a.stats->nfe, 2 + 6 * (nacc + nrej));
-        atomicMax(&a.stats->n_accepted, nacc);
-        atomicMax(&a.stats->n_rejected, nrej);
-        atomicMax(&a.stats->evals_run, nrun);
-        a.stats->last_dt = (float)dt;
-        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(a.rows * (long)nrun));
-    }
+    grid_cleanup(gs, red, tid);
+    write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
 }
 
 // sum slot `which` of every workgroup region in a fixed order and undo the block layout: out[canonical parameter index]
 template <int D>
 __global__ void wide_reduce_kernel(const float* __restrict__ regions, int nwg, int which, int valid, float* __restrict__ out) {
-    using SI = WideSmallIdx<D>;
     const ParamLayout L = make_layout(D, kWH);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= L.total) return;

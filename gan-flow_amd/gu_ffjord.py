@@ -156,6 +156,9 @@ class FusedTrainStep:
         dev = example_batch.device
         self.adam_state = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in self.flats]
         self.stats = torch.zeros(len(self.blocks), 2, 8, dtype=torch.int32, device=dev)   # [block][fwd, bwd][CnfStats words]
+        # a workspace of its own, zero-initialised and only ever used by CNF_FLAG_CLEAN calls: the solves enqueue no memsets
+        need = max(_native.workspace_bytes(_inner(blk.odefunc).net_desc(), example_batch.shape[0]) for blk in self.blocks)
+        self.workspace = torch.zeros(need, dtype=torch.uint8, device=dev)
         self.static_x = example_batch.clone()
         self.static_loss = None
         self.graph = None
@@ -192,12 +195,15 @@ class FusedTrainStep:
         z, lp, tape = self.static_x, None, []
         for i, blk in enumerate(self.blocks):
             net, t0, t1, opts, e = blk.solve_plan(z, reset_counter=False)
-            z, lp, _ = nat.solve_fwd(net, self.flats[i], z, lp, t0, t1, opts, e, stats=self.stats[i, 0])
+            if opts.solver == 0 and opts.tile_rows == 0:
+                opts.flags |= nat.FLAG_CLEAN
+            z, lp, _ = nat.solve_fwd(net, self.flats[i], z, lp, t0, t1, opts, e, stats=self.stats[i, 0], workspace=self.workspace)
             tape.append((net, t0, t1, opts, e, z, lp))
         loss, gz, gl = nat.nll_loss(z, lp)
         for i in range(len(self.blocks) - 1, -1, -1):
             net, t0, t1, opts, e, z1, lp1 = tape[i]
-            gz, gl, gp, _ = nat.solve_bwd(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, e, stats=self.stats[i, 1])
+            gz, gl, gp, _ = nat.solve_bwd(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, e, stats=self.stats[i, 1],
+                                          workspace=self.workspace)
             nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], **self.hyper)
         return loss
 

@@ -12,7 +12,7 @@
  *   - every pointer is a BORROWED DEVICE pointer (fp32, contiguous row-major) unless marked "host";
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *   - the library never allocates device memory: the caller passes a workspace of
- *     cnf_workspace_bytes() bytes (16-byte aligned) that the call zeroes and uses;
+ *     cnf_workspace_bytes() bytes (16-byte aligned) that the call zeroes and uses (see CNF_FLAG_CLEAN);
  *   - return value 0 = enqueued; non-zero = rejected before launch, message in cnf_last_error();
  *   - run-time failures of the integrator (step underflow, non-finite state, step limit) are
  *     reported in CnfStats.status, which lives in device memory and is read by the caller after
@@ -57,7 +57,16 @@ typedef struct CnfSolverOpts {
                             semantics); 16 = every 16-row tile controls its own step (throughput
                             evaluation mode)                              */
     int32_t max_steps;   /* dopri5 attempt limit per solve (0 = 1<<20)                            */
+    int32_t flags;       /* CNF_FLAG_* (0 = none)                                                 */
 } CnfSolverOpts;
+
+/* CNF_FLAG_CLEAN: the caller guarantees that the first 16 KiB + 64 bytes of `workspace` are zero and that
+ * stats->status is zero -- true for a zero-initialised workspace / stats block that only flagged calls have used
+ * since (every batch-global dopri5 solve leaves those bytes zero again when it ends, a failed one included unless
+ * it timed out).  The call then enqueues no memset at all: tight loops and captured graphs save four fill nodes
+ * per training iteration.  stats->status becomes sticky (it is only ever raised).  Ignored (memsets kept) where it
+ * does not apply: rk4, tile-local control, more than 4096 rows.                                            */
+enum { CNF_FLAG_CLEAN = 1 };
 
 enum {
     CNF_OK = 0,
