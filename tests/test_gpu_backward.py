@@ -255,3 +255,38 @@ def test_solves_do_not_depend_on_stale_lds(dim, hutch, rows):
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dim,hidden,rows", [(2, 64, 2048), (2, 64, 100), (16, 64, 512), (2, 256, 300)])
+def test_flag_clean_calls_match_zeroing_calls(dim, hidden, rows):
+    """CNF_FLAG_CLEAN (include/cnf_hip.h): on a zero-initialised workspace / stats block the solves enqueue no memset
+    and leave the workspace head clean again.  Three flagged forward + adjoint rounds on ONE workspace give exactly the
+    results of ordinary (zeroing) calls, the head of the workspace is zero after every call, and counters of a later,
+    shorter solve replace those of an earlier one (no stale maxima)."""
+    nat = _native()
+    hutch = dim == 16
+    g = torch.Generator().manual_seed(41)
+    m = oracle_random_model(dim, seed=9, divergence_fn="approximate" if hutch else "brute_force", scale=1.5,
+                            hidden_dims=(hidden,) * 3)
+    net = nat.net_desc(dim, hidden, 3, hutch)
+    params = _flat(m).to(DEV)
+    x = torch.randn(rows, dim, generator=g).to(DEV)
+    e = torch.randn(rows, dim, generator=g).to(DEV) if hutch else None
+    ws = torch.zeros(nat.workspace_bytes(net, rows), dtype=torch.uint8, device=DEV)
+    st = torch.zeros(2, 8, dtype=torch.int32, device=DEV)
+    head = 16384 + 64
+    for T in (0.5, 0.5, 0.05):      # the last round is a much shorter solve: fewer steps than the rounds before
+        ref_o = nat.make_opts("dopri5", 1e-5, 1e-5)
+        z_r, l_r, sf_r = nat.solve_fwd(net, params, x, None, 0.0, T, ref_o, e)
+        gx_r, gl_r, gp_r, sb_r = nat.solve_bwd(net, params, z_r, l_r, z_r / rows, torch.full_like(l_r, 1.0 / rows), 0.0, T, ref_o, e)
+        o = nat.make_opts("dopri5", 1e-5, 1e-5, flags=nat.FLAG_CLEAN)
+        z, l, sf = nat.solve_fwd(net, params, x, None, 0.0, T, o, e, stats=st[0], workspace=ws)
+        torch.cuda.synchronize()
+        assert int(ws[:head].max()) == 0
+        gx, gl, gp, sb = nat.solve_bwd(net, params, z, l, z / rows, torch.full_like(l, 1.0 / rows), 0.0, T, o, e, stats=st[1], workspace=ws)
+        torch.cuda.synchronize()
+        assert int(ws[:head].max()) == 0
+        for a, b in ((z, z_r), (l, l_r), (gx, gx_r), (gp, gp_r), (sf, sf_r), (sb, sb_r)):
+            assert torch.equal(a.cpu(), b.cpu())
+        assert nat.Stats(sf).status == 0 and nat.Stats(sb).status == 0
+    assert nat.Stats(sb).n_accepted < 3
