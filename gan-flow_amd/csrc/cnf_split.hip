@@ -1106,19 +1106,29 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------
-__global__ void reduce_slab_split_kernel(const float* __restrict__ slab, int nwg, int P, float* __restrict__ out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four fixed partial chains: deterministic, 4 loads in flight
-    int g = 0;
-    for (; g + 3 < nwg; g += 4) {
-        s0 += slab[(size_t)g * P + p];
-        s1 += slab[(size_t)(g + 1) * P + p];
-        s2 += slab[(size_t)(g + 2) * P + p];
-        s3 += slab[(size_t)(g + 3) * P + p];
+// Sum of the workgroups' slabs in a FIXED order (deterministic gradients).  64 parameters per block; the four waves
+// of a block take the slabs g = wave, wave + 4, ... (eight independent loads in flight per thread), LDS combines the
+// four partial sums as (w0 + w1) + (w2 + w3).
+__global__ __launch_bounds__(256) void reduce_slab_split_kernel(const float* __restrict__ slab, int nwg, int P,
+                                                                float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (p < P) {
+        int g = wv;
+        for (; g + 28 < nwg; g += 32) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = slab[(size_t)(g + 4 * k) * P + p];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        for (; g < nwg; g += 4) acc += slab[(size_t)g * P + p];
     }
-    for (; g < nwg; ++g) s0 += slab[(size_t)g * P + p];
-    out[p] = (s0 + s1) + (s2 + s3);
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && p < P) out[p] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 template <int D, bool HUTCH>
@@ -1147,7 +1157,7 @@ static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     const int P = make_layout(D, kH).total;
-    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 127) / 128), dim3(128), 0, s, a.slab, grid, P, a.grad_params);
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, a.slab, grid, P, a.grad_params);
     return hipGetLastError();
 }
 
@@ -1167,7 +1177,7 @@ static hipError_t split_aug_t(const SolveArgs& a, float t, const float* z, const
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     const int P = make_layout(D, kH).total;
-    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 127) / 128), dim3(128), 0, s, a.slab, grid, P, a.grad_params);
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, a.slab, grid, P, a.grad_params);
     return hipGetLastError();
 }
 
