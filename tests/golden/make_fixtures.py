@@ -21,209 +21,17 @@ Outputs (committed; data only):
 
 Run from the repo root:  python tests/golden/make_fixtures.py
 """
-import io
 import json
 import os
-import pickletools
-import struct
 import sys
 
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gan_flow_amd.legacy_checkpoint import read_checkpoint  # noqa: E402  (the non-executing reader lives in the package)
+
 REF = "/root/reference/model_results"
 HERE = os.path.dirname(os.path.abspath(__file__))
-
-
-class _Mark:
-    pass
-
-
-def inert_tree(buf, start):
-    """Fold the opcode listing of ONE pickle starting at `start` into inert primitives.
-
-    Returns (tree, end_offset).  Nothing is imported, called or instantiated: callables named in the
-    stream are kept as ('global', 'module name') tuples and applications of them as tagged tuples.
-    """
-    bio = io.BytesIO(buf)
-    bio.seek(start)
-    stack, memo = [], {}
-
-    def pop_to_mark():
-        items = []
-        while not isinstance(stack[-1], _Mark):
-            items.append(stack.pop())
-        stack.pop()
-        items.reverse()
-        return items
-
-    for op, arg, _pos in pickletools.genops(bio):
-        n = op.name
-        if n == "PROTO":
-            pass
-        elif n == "MARK":
-            stack.append(_Mark())
-        elif n in ("BINUNICODE", "SHORT_BINUNICODE", "BININT", "BININT1", "BININT2", "BINFLOAT", "LONG1",
-                   "SHORT_BINSTRING", "BINSTRING", "LONG4"):
-            stack.append(arg)
-        elif n == "NONE":
-            stack.append(None)
-        elif n == "NEWTRUE":
-            stack.append(True)
-        elif n == "NEWFALSE":
-            stack.append(False)
-        elif n == "GLOBAL":
-            stack.append(("global", arg))
-        elif n in ("BINPUT", "LONG_BINPUT"):
-            memo[arg] = stack[-1]
-        elif n in ("BINGET", "LONG_BINGET"):
-            stack.append(memo[arg])
-        elif n == "EMPTY_TUPLE":
-            stack.append(())
-        elif n == "TUPLE":
-            stack.append(tuple(pop_to_mark()))
-        elif n == "TUPLE1":
-            stack[-1:] = [(stack[-1],)]
-        elif n == "TUPLE2":
-            stack[-2:] = [(stack[-2], stack[-1])]
-        elif n == "TUPLE3":
-            stack[-3:] = [(stack[-3], stack[-2], stack[-1])]
-        elif n == "EMPTY_DICT":
-            stack.append({})
-        elif n == "EMPTY_LIST":
-            stack.append([])
-        elif n == "APPEND":
-            v = stack.pop()
-            _seq(stack[-1]).append(v)
-        elif n == "APPENDS":
-            items = pop_to_mark()
-            _seq(stack[-1]).extend(items)
-        elif n == "SETITEM":
-            v = stack.pop()
-            k = stack.pop()
-            _map(stack[-1])[k] = v
-        elif n == "SETITEMS":
-            items = pop_to_mark()
-            d = _map(stack[-1])
-            for i in range(0, len(items), 2):
-                d[items[i]] = items[i + 1]
-        elif n == "BINPERSID":
-            stack[-1] = ("pers", stack[-1])
-        elif n == "REDUCE":
-            args = stack.pop()
-            fn = stack.pop()
-            stack.append(["reduce", fn, args, {}, []])  # [tag, fn, args, items, state]
-        elif n == "NEWOBJ":
-            args = stack.pop()
-            cls = stack.pop()
-            stack.append(["obj", cls, args, {}, []])
-        elif n == "BUILD":
-            state = stack.pop()
-            stack[-1][4].append(state)
-        elif n == "STOP":
-            return stack.pop(), bio.tell()
-        else:
-            raise ValueError("opcode %s not expected in a torch<=1.5 checkpoint" % n)
-    raise ValueError("no STOP")
-
-
-def _map(node):
-    return node if isinstance(node, dict) else node[3]        # OrderedDict() stand-in keeps items in [3]
-
-
-def _seq(node):
-    return node if isinstance(node, list) and (not node or node[0] not in ("reduce", "obj")) else node[3].setdefault("_list", [])
-
-
-def _is(node, tag):
-    return isinstance(node, list) and len(node) == 5 and node[0] == tag
-
-
-def _global_name(node):
-    if isinstance(node, tuple) and len(node) == 2 and node[0] == "global":
-        return node[1]
-    if isinstance(node, tuple) and len(node) == 2 and node[0] == "pers":
-        # ('module', <global>, source_path, None) persistent id of a class
-        return node[1][1][1]
-    return None
-
-
-def tensor_meta(node):
-    """-> (storage_key, numel_storage, offset, size, stride, requires_grad) or None."""
-    if not _is(node, "reduce"):
-        return None
-    fn = _global_name(node[1])
-    if fn == "torch._utils _rebuild_parameter":
-        inner = tensor_meta(node[2][0])
-        return inner[:5] + (bool(node[2][1]),)
-    if fn == "torch._utils _rebuild_tensor_v2":
-        pers, offset, size, stride, rg = node[2][0], node[2][1], node[2][2], node[2][3], node[2][4]
-        _tag, _cls, key, _dev, numel, _view = pers[1]
-        return (key, numel, offset, tuple(size), tuple(stride), bool(rg))
-    return None
-
-
-def module_state(node):
-    assert _is(node, "obj"), node
-    st = {}
-    for s in node[4]:
-        st.update(s)
-    return st
-
-
-def walk_modules(node, prefix, tensors, attrs):
-    st = module_state(node)
-    cls = _global_name(node[1])
-    attrs[prefix.rstrip(".") or "<root>"] = {"class": cls}
-    for group in ("_parameters", "_buffers"):
-        for name, t in _map(st.get(group, {})).items():
-            if t is None:
-                continue
-            tensors[prefix + name] = tensor_meta(t)
-    for k, v in st.items():
-        if k.startswith("_") and k in ("_parameters", "_buffers", "_modules", "_backward_hooks", "_forward_hooks",
-                                       "_forward_pre_hooks", "_state_dict_hooks", "_load_state_dict_pre_hooks"):
-            continue
-        tm = tensor_meta(v)
-        if tm is not None:
-            attrs[prefix.rstrip(".") or "<root>"][k] = {"tensor_shape": list(tm[3])}
-        elif isinstance(v, (int, float, str, bool, type(None))):
-            attrs[prefix.rstrip(".") or "<root>"][k] = v
-        elif isinstance(v, (tuple, list, dict)) and not _is(v, "obj") and not _is(v, "reduce"):
-            name = _global_name(v)
-            attrs[prefix.rstrip(".") or "<root>"][k] = ("<global %s>" % name) if name else json.loads(json.dumps(v, default=str))
-    for name, child in _map(st.get("_modules", {})).items():
-        walk_modules(child, prefix + name + ".", tensors, attrs)
-
-
-def read_checkpoint(path):
-    buf = open(path, "rb").read()
-    pos = 0
-    trees = []
-    for _ in range(5):            # magic, protocol, sys-info, model, storage keys  (SURVEY.md Appendix A)
-        tree, pos = inert_tree(buf, pos)
-        trees.append(tree)
-    assert trees[0] == 0x1950A86A20F9469CFC6C and trees[1] == 1001, "not a legacy torch checkpoint"
-    assert trees[2]["little_endian"] is True
-    keys = trees[4]
-    storages = {}
-    for key in keys:
-        (numel,) = struct.unpack_from("<q", buf, pos)
-        pos += 8
-        storages[key] = np.frombuffer(buf, dtype="<f4", count=numel, offset=pos).copy()
-        pos += 4 * numel
-    assert pos == len(buf), (pos, len(buf))
-    tensors, attrs = {}, {}
-    walk_modules(trees[3], "", tensors, attrs)
-    arrays = {}
-    for name, (key, numel, offset, size, stride, _rg) in tensors.items():
-        st = storages[key]
-        assert st.size == numel
-        n = int(np.prod(size)) if size else 1
-        # all tensors in these files are contiguous
-        expect = tuple(int(np.prod(size[i + 1:])) for i in range(len(size)))
-        assert tuple(stride) == expect, (name, size, stride)
-        arrays[name] = st[offset:offset + n].reshape(size).astype(np.float32)
-    return arrays, attrs
 
 
 def main():

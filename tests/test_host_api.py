@@ -127,3 +127,45 @@ def test_gaussian_mixture_data_config5():
     assert not torch.equal(xa, GaussianMixture(16, sample_seed=6).get_sample(4096))
     h = a.entropy_estimate(100000)
     assert abs(h - (8 * (1 + math.log(2 * math.pi)) + math.log(8))) < 0.1
+
+
+def test_legacy_checkpoint_reader_round_trip(tmp_path):
+    """a legacy (torch <= 1.5 layout) whole-module checkpoint is read WITHOUT unpickling -- opcode
+    listing + raw storages -- and rebuilt into the library's modules.  The file here is written by this test (same
+    layout: torch.save(model, legacy serialization)); the reference's own files are covered by the next test."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.legacy_checkpoint import load_legacy_ffjord, read_checkpoint
+    torch.manual_seed(3)
+    m = gu_ffjord.build_model(2, dims=(64, 64, 64), num_blocks=2, divergence_fn="approximate", atol=1e-4, rtol=1e-3)
+    path = str(tmp_path / "ffjord.pth")
+    torch.save(m, path, _use_new_zipfile_serialization=False)
+    arrays, attrs = read_checkpoint(path)
+    sd = m.state_dict()
+    assert set(arrays) == set(sd) and all(np.array_equal(arrays[k], sd[k].numpy()) for k in sd)
+    assert attrs["chain.1"]["solver"] == "dopri5" and attrs["chain.1"]["atol"] == 1e-4
+    m2 = load_legacy_ffjord(path)
+    assert len(m2.chain) == 2 and m2.chain[0].atol == 1e-4 and m2.chain[0].rtol == 1e-3 and not m2.training
+    assert m2.chain[0].odefunc.odefunc.divergence_fn.__name__ == "divergence_approx"
+    assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), sd.values()))
+    with open(path, "rb") as f:
+        blob = f.read()
+    bad = tmp_path / "bad.pth"
+    bad.write_bytes(b"\x80\x02K\x01." + blob[5:])          # wrong magic number
+    with pytest.raises((AssertionError, ValueError)):      # not a legacy torch checkpoint: refused, nothing executed
+        read_checkpoint(str(bad))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/model_results/unimodal/ffjord.pth"),
+                    reason="the reference's checkpoints exist only in the build container")
+@pytest.mark.parametrize("which", ["unimodal", "multimodal"])
+def test_legacy_checkpoint_reader_on_reference_files(which):
+    """The reference's trained models (model_plot.py:72-74 loads them with torch.load): read without unpickling, equal
+    to the committed fixtures, rebuilt with the stored solver settings."""
+    from gan_flow_amd.legacy_checkpoint import load_legacy_ffjord
+    m = load_legacy_ffjord("/root/reference/model_results/%s/ffjord.pth" % which)
+    ref = fixture_state_dict(which)
+    sd = m.state_dict()
+    assert set(sd) == set(ref) and all(torch.equal(sd[k], ref[k]) for k in ref)
+    blk = m.chain[0]
+    assert (blk.solver, blk.atol, blk.rtol, blk.test_solver) == ("dopri5", 1e-5, 1e-5, "dopri5")
+    assert abs(float(blk.sqrt_end_time.detach()) ** 2 - 0.5) < 1e-6
