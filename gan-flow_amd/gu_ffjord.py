@@ -99,7 +99,7 @@ class GraphedTrainStep:
         self.nfe = torch.zeros(2, dtype=torch.int64, device=example_batch.device)   # running sums: forward, backward
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may call HIP
             self.static_loss = self._eager()
             st = [model.chain[0].last_stats["forward"], model.chain[0].last_stats["backward"]]
             self.nfe += torch.stack([st[0][1], st[1][1]]).to(torch.int64)
@@ -175,7 +175,7 @@ class FusedTrainStep:
             torch.cuda.synchronize()
             self.check()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may call HIP
                 self.static_loss = self._iteration()
         else:
             for xb in warmup_batches:

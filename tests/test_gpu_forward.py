@@ -304,3 +304,55 @@ def test_round_trip_large_batch_property():
         # bar is on the bulk (mean, 99.9th percentile), with a loose sanity bound on the single worst row.
         assert (zb - z0).abs().max() < 2e-2 and (zb - z0).abs().mean() < 1e-3
         assert lb.abs().mean() < 1e-2 and torch.quantile(lb.abs().flatten(), 0.999) < 0.15 and lb.abs().max() < 3.0
+
+
+@pytest.mark.parametrize("hidden", [64, 256])
+def test_solver_failures_and_bad_calls_are_reported(hidden):
+    """Error behaviour at the boundary: calls the library cannot run are rejected before launch
+    with a message; integrator failures come back in CnfStats.status and raise with torchdiffeq's wording."""
+    nat = _native()
+    m = oracle_random_model(2, seed=1, scale=2.0, hidden_dims=(hidden,) * 3)
+    net = nat.net_desc(2, hidden, 3, False)
+    params = _flat(m).to(DEV)
+    x = torch.randn(64, 2, generator=torch.Generator().manual_seed(0)).to(DEV)
+    ok = nat.make_opts("dopri5", 1e-5, 1e-5)
+    # -- rejected before launch
+    with pytest.raises(nat.CnfError, match="rows must be positive"):
+        nat.solve_fwd(net, params, x[:0], None, 0.0, 0.5, ok)
+    with pytest.raises(nat.CnfError, match="finite and distinct"):
+        nat.solve_fwd(net, params, x, None, 0.5, 0.5, ok)
+    with pytest.raises(nat.CnfError, match="rtol > 0"):
+        nat.solve_fwd(net, params, x, None, 0.0, 0.5, nat.make_opts("dopri5", 0.0, 1e-5))
+    with pytest.raises(nat.CnfError, match="tile_rows"):
+        nat.solve_fwd(net, params, x, None, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5, tile_rows=8))
+    with pytest.raises(nat.CnfError, match="params must have shape"):
+        nat.solve_fwd(net, params[:-1], x, None, 0.0, 0.5, ok)
+    with pytest.raises(nat.CnfError, match="unsupported net"):
+        nat.param_count(nat.net_desc(2, 128, 3, False))
+    with pytest.raises(nat.CnfError, match="Hutchinson divergence needs the probe"):
+        nat.solve_fwd(nat.net_desc(2, hidden, 3, True), params, x, None, 0.0, 0.5, ok)
+    with pytest.raises(nat.CnfError, match="float32"):
+        nat.solve_fwd(net, params, x.double(), None, 0.0, 0.5, ok)
+    # -- integrator failures (status words), batch-global and tile-local control
+    for tile in (0, 16):
+        z, l, st = nat.solve_fwd(net, params, x, None, 0.0, 0.5, nat.make_opts("dopri5", 1e-9, 1e-9, tile_rows=tile, max_steps=3))
+        with pytest.raises(nat.CnfError, match="max_num_steps exceeded"):
+            nat.Stats(st).raise_for_status()
+        xn = x.clone()
+        xn[5, 1] = float("nan")
+        z, l, st = nat.solve_fwd(net, params, xn, None, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5, tile_rows=tile))
+        s = nat.Stats(st)
+        assert s.status in (1, 2)       # torchdiffeq: "non-finite values in state `y`" or, via NaN step sizes, "underflow in dt"
+        with pytest.raises(nat.CnfError, match="non-finite values|underflow in dt"):
+            s.raise_for_status()
+        if tile == 16:                  # the other tiles are unaffected by the poisoned one
+            good = torch.ones(64, dtype=torch.bool)
+            good[0:16] = False
+            z_ok, _, st_ok = nat.solve_fwd(net, params, x, None, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5, tile_rows=16))
+            assert torch.equal(z[good.to(DEV)], z_ok[good.to(DEV)])
+    # the adjoint refuses what it cannot do
+    z1, l1, _ = nat.solve_fwd(net, params, x, None, 0.0, 0.5, ok)
+    with pytest.raises(nat.CnfError, match="dopri5 only"):
+        nat.solve_bwd(net, params, z1, l1, z1, l1, 0.0, 0.5, nat.make_opts("rk4", step_size=0.1))
+    with pytest.raises(nat.CnfError, match="batch-global"):
+        nat.solve_bwd(net, params, z1, l1, z1, l1, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5, tile_rows=16))
