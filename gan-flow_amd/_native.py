@@ -30,7 +30,7 @@ class CnfAdamOpts(ctypes.Structure):
                 ("weight_decay", ctypes.c_double)]
 
 
-SOLVER_IDS = {"dopri5": 0, "rk4": 1}
+SOLVER_IDS = {"dopri5": 0, "rk4": 1, "euler": 2, "midpoint": 3}
 DIV_EXACT, DIV_HUTCHINSON = 0, 1
 STATUS_MESSAGES = {
     1: "underflow in dt {last_dt}",

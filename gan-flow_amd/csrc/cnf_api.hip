@@ -179,7 +179,8 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
             return fail("%s: batch-global step control supports at most %d rows per solve (got %ld); split the batch into "
                         "chunks as the reference's evaluation does, or use tile_rows=%d", who,
                         cnf::kMaxWG * cnf::kRowsPerWG, (long)rows, cnf::kRows);
-    } else if (opts->solver == CNF_SOLVER_RK4) {
+    } else if (opts->solver == CNF_SOLVER_RK4 || opts->solver == CNF_SOLVER_EULER || opts->solver == CNF_SOLVER_MIDPOINT) {
+        a.fixed_kind = opts->solver;
         if (opts->step_size > 0.f) {
             // the fixed grid of torchdiffeq: ceil((t1-t0)/h + 1) points, the last clipped to t1 (fp32 arithmetic)
             const float sgn = t1 >= t0 ? 1.f : -1.f;
@@ -187,9 +188,9 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
             const float span = tau1 - tau0;
             const float q = span / opts->step_size;
             const float npts = std::ceil(q + 1.0f);
-            if (!(npts >= 2.f) || npts > 1e7f) return fail("%s: rk4 step_size gives an unusable grid (%g points)", who, npts);
+            if (!(npts >= 2.f) || npts > 1e7f) return fail("%s: step_size gives an unusable grid (%g points)", who, npts);
             const float last = (npts - 1.0f) * opts->step_size + tau0;
-            if (last < tau1) return fail("%s: rk4 grid does not reach t1 (torchdiffeq asserts time_grid[-1] == t[-1])", who);
+            if (last < tau1) return fail("%s: fixed grid does not reach t1 (torchdiffeq asserts time_grid[-1] == t[-1])", who);
             a.n_grid = (int)npts - 1;
             a.step_size = opts->step_size;
         }

@@ -15,7 +15,8 @@ struct SolveArgs {
     float t0, t1;
     float rtol, atol;
     float step_size;      // rk4 grid spacing (only read when n_grid > 1)
-    int n_grid;           // rk4 number of steps
+    int n_grid;           // fixed-grid solvers: number of steps
+    int fixed_kind;       // CNF_SOLVER_RK4 (3/8 rule) | CNF_SOLVER_EULER | CNF_SOLVER_MIDPOINT
     int max_steps;
     unsigned long long* gran;  // grid-reduction granules, zeroed before the launch
     CnfStats* stats;           // zeroed before the launch

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(kThreads) void wide_rk4_kernel(SolveArgs a) {
         float ti = ta;
 #pragma unroll
         for (int c = 0; c < C; ++c) yi[c] = y[c];
-        for (int st = 0; st < 4; ++st) {
+        const int nst = a.fixed_kind == CNF_SOLVER_EULER ? 1 : (a.fixed_kind == CNF_SOLVER_MIDPOINT ? 2 : 4);
+        for (int st = 0; st < nst; ++st) {
             float zz[D], f[D], div, k[C];
 #pragma unroll
             for (int m = 0; m < D; ++m) zz[m] = yi[m];
@@ -219,7 +220,19 @@ __global__ __launch_bounds__(kThreads) void wide_rk4_kernel(SolveArgs a) {
 #pragma unroll
             for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
             k[D] = -sgn * div;
-            if (st == 0) {
+            if (a.fixed_kind == CNF_SOLVER_EULER) {            // y + dt f(t, y)
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+            } else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) {  // y + dt f(t + dt/2, y + f(t, y) dt/2)
+                if (st == 0) {
+                    ti = ta + dt / 2;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) yi[c] = y[c] + k[c] * dt / 2;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+                }
+            } else if (st == 0) {
                 ti = ta + dt / 3;
 #pragma unroll
                 for (int c = 0; c < C; ++c) { k1[c] = k[c]; yi[c] = y[c] + dt * k[c] / 3; }
@@ -243,11 +256,12 @@ __global__ __launch_bounds__(kThreads) void wide_rk4_kernel(SolveArgs a) {
         a.logp_out[row] = y[D];
     }
     if (tid == 0) {
-        atomicMax(&a.stats->nfe, 4 * a.n_grid);
+        const int nst_total = a.fixed_kind == CNF_SOLVER_EULER ? 1 : (a.fixed_kind == CNF_SOLVER_MIDPOINT ? 2 : 4);
+        atomicMax(&a.stats->nfe, nst_total * a.n_grid);
         atomicMax(&a.stats->n_accepted, a.n_grid);
-        atomicMax(&a.stats->evals_run, 4 * a.n_grid);
+        atomicMax(&a.stats->evals_run, nst_total * a.n_grid);
         long nrow = a.rows - base < kRows ? a.rows - base : kRows;
-        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(nrow * 4 * a.n_grid));
+        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(nrow * nst_total * a.n_grid));
     }
 }
 
@@ -480,7 +494,7 @@ template <int D, bool HUTCH>
 static hipError_t wide_solve_t(const SolveArgs& a, int solver, bool global, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
     dbg_timing_begin(s);
-    if (solver == CNF_SOLVER_RK4) {
+    if (solver != CNF_SOLVER_DOPRI5) {
         hipLaunchKernelGGL((wide_rk4_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
     } else if (global) {
         hipLaunchKernelGGL((wide_dopri5_kernel<D, HUTCH, true>), dim3(grid), dim3(kThreads), 0, s, a);

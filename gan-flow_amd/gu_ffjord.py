@@ -254,7 +254,7 @@ def parse_args(argv=None):
     p.add_argument("--time_length", type=float, default=0.5)
     p.add_argument("--train_T", type=eval, default=True, choices=[True, False])
     p.add_argument("--divergence_fn", type=str, default="brute_force", choices=["brute_force", "approximate"])
-    p.add_argument("--solver", type=str, default="dopri5", choices=["dopri5", "rk4"])
+    p.add_argument("--solver", type=str, default="dopri5", choices=["dopri5", "rk4", "euler", "midpoint"])
     p.add_argument("--atol", type=float, default=1e-5)
     p.add_argument("--rtol", type=float, default=1e-5)
     p.add_argument("--step_size", type=float, default=None)

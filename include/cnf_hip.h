@@ -45,14 +45,14 @@ typedef struct CnfNetDesc {
                            (`divergence_approx`, probe `e` fixed for the whole solve)           */
 } CnfNetDesc;
 
-enum { CNF_SOLVER_DOPRI5 = 0, CNF_SOLVER_RK4 = 1 };
+enum { CNF_SOLVER_DOPRI5 = 0, CNF_SOLVER_RK4 = 1, CNF_SOLVER_EULER = 2, CNF_SOLVER_MIDPOINT = 3 };   /* 1..3: fixed grid */
 enum { CNF_DIV_EXACT = 0, CNF_DIV_HUTCHINSON = 1 };
 
 /* Solver options: the keyword arguments of torchdiffeq.odeint (rtol, atol, method, options). */
 typedef struct CnfSolverOpts {
     int32_t solver;      /* CNF_SOLVER_*                                                          */
     float rtol, atol;    /* dopri5 tolerances (the same pair for z and logp, as CNF passes them)   */
-    float step_size;     /* rk4: options['step_size']; <= 0 means one step over [t0, t1]           */
+    float step_size;     /* fixed-grid solvers: options['step_size']; <= 0 means one step over [t0, t1] */
     int32_t tile_rows;   /* dopri5 step control: 0 = one step size for the whole batch (reference
                             semantics); 16 = every 16-row tile controls its own step (throughput
                             evaluation mode)                              */

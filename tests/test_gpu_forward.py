@@ -356,3 +356,17 @@ def test_solver_failures_and_bad_calls_are_reported(hidden):
         nat.solve_bwd(net, params, z1, l1, z1, l1, 0.0, 0.5, nat.make_opts("rk4", step_size=0.1))
     with pytest.raises(nat.CnfError, match="batch-global"):
         nat.solve_bwd(net, params, z1, l1, z1, l1, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5, tile_rows=16))
+
+
+@pytest.mark.parametrize("solver", ["euler", "midpoint"])
+@pytest.mark.parametrize("dim,hutch,rows", [(2, False, 300), (16, True, 100), (1, False, 33)])
+def test_other_fixed_grid_solvers_parity(solver, dim, hutch, rows):
+    """euler / midpoint on the same fixed grid as rk4 (the other torchdiffeq fixed-grid solvers)."""
+    m = oracle_random_model(dim, seed=1, divergence_fn="approximate" if hutch else "brute_force", scale=1.5)
+    m.train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(rows, dim, generator=g)
+    e = torch.randn(rows, dim, generator=g) if hutch else None
+    (z_ref, l_ref, _), (z, l, st) = _solve_pair(m, x, False, solver, step_size=0.02, hutch=hutch, e=e)
+    assert rel_err(z, z_ref) < 1e-5 and rel_err(l, l_ref) < 1e-5
+    assert st.nfe == (1 if solver == "euler" else 2) * st.n_accepted == (1 if solver == "euler" else 2) * 25

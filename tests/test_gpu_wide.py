@@ -79,16 +79,17 @@ def _solve_pair(m, x, solver, step_size=None, tile_rows=0, hutch=False, e=None, 
     return (z_ref[1], l_ref[1], stats), (z.cpu(), l.cpu(), st)
 
 
+@pytest.mark.parametrize("solver,stages", [("rk4", 4), ("euler", 1), ("midpoint", 2)])
 @pytest.mark.parametrize("dim,hutch,rows", [(2, False, 1000), (2, True, 50), (1, False, 17)])
-def test_wide_rk4_parity(dim, hutch, rows):
+def test_wide_fixed_grid_parity(solver, stages, dim, hutch, rows):
     m = _model(dim, hutch, seed=1)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(rows, dim, generator=g)
     e = torch.randn(rows, dim, generator=g) if hutch else None
-    (z_ref, l_ref, _), (z, l, st) = _solve_pair(m, x, "rk4", step_size=0.05, hutch=hutch, e=e)
-    print("wide rk4 d=%d: z %.1e logp %.1e" % (dim, rel_err(z, z_ref), rel_err(l, l_ref)))
+    (z_ref, l_ref, _), (z, l, st) = _solve_pair(m, x, solver, step_size=0.05, hutch=hutch, e=e)
+    print("wide %s d=%d: z %.1e logp %.1e" % (solver, dim, rel_err(z, z_ref), rel_err(l, l_ref)))
     assert rel_err(z, z_ref) < 1e-5 and rel_err(l, l_ref) < 1e-5
-    assert st.nfe == 4 * st.n_accepted == 40
+    assert st.nfe == stages * st.n_accepted == stages * 10
 
 
 @pytest.mark.parametrize("dim,hutch,rows,reverse", [(2, False, 2048, False), (2, False, 333, True), (2, True, 96, False),
