@@ -86,6 +86,20 @@ int check_net(const CnfNetDesc* n) {
 
 long n_wg(long rows) { return (rows + cnf::kRowsPerWG - 1) / cnf::kRowsPerWG; }
 
+// Compute units of the current device (cached per device).  The grid-wide reductions of batch-global step control spin
+// on every workgroup of the launch, so all of them must be resident at once: at most one workgroup per CU is assumed.
+int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return cnf::kMaxWG;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = cnf::kMaxWG;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // batch-global solves of up to 16*256 rows run one tile per workgroup (cnf_split.hip): every workgroup resident
 bool use_split(const CnfNetDesc* n, long rows) {
     return rows <= (long)cnf::kRows * cnf::kMaxWG;
@@ -179,6 +193,12 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
             return fail("%s: batch-global step control supports at most %d rows per solve (got %ld); split the batch into "
                         "chunks as the reference's evaluation does, or use tile_rows=%d", who,
                         cnf::kMaxWG * cnf::kRowsPerWG, (long)rows, cnf::kRows);
+        if (global) {
+            const long wgs = (is_wide(net) || use_split(net, rows)) ? (rows + cnf::kRows - 1) / cnf::kRows : n_wg(rows);
+            if (wgs > 1 && wgs > device_cus())
+                return fail("%s: batch-global step control needs %ld co-resident workgroups but the device has %d compute units; "
+                            "split the batch or use tile_rows=%d", who, wgs, device_cus(), cnf::kRows);
+        }
     } else if (opts->solver == CNF_SOLVER_RK4 || opts->solver == CNF_SOLVER_EULER || opts->solver == CNF_SOLVER_MIDPOINT) {
         a.fixed_kind = opts->solver;
         if (opts->step_size > 0.f) {

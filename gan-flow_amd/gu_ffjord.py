@@ -289,7 +289,7 @@ def main(argv=None):
         x = data.get_sample(args.batch_size).to(device)
         fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay)
     else:
-        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=True)
     t_last = time.time()
     for itr in range(1, args.niters + 1):
         x = data.get_sample(args.batch_size).to(device)
