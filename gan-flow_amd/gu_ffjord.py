@@ -239,6 +239,17 @@ class FusedTrainStep:
     def step_count(self):
         return int(self.adam_state[0][0].item())
 
+    def state_dict(self):
+        """Optimizer state (Adam moments and step counts per block) for checkpoint / resume."""
+        return {"exp_avg": [t.clone() for t in self.exp_avg], "exp_avg_sq": [t.clone() for t in self.exp_avg_sq],
+                "step": [int(s[0].item()) for s in self.adam_state], "hyper": dict(self.hyper)}
+
+    def load_state_dict(self, state):
+        for dst, src in zip(self.exp_avg + self.exp_avg_sq, list(state["exp_avg"]) + list(state["exp_avg_sq"])):
+            dst.copy_(src)
+        for s, n in zip(self.adam_state, state["step"]):
+            s.copy_(torch.tensor([int(n), 0], dtype=torch.int32))
+
 
 def parse_args(argv=None):
     p = argparse.ArgumentParser("FFJORD CNF on the Gaussian-uniform mixture (MI355X HIP path)")
@@ -261,6 +272,9 @@ def parse_args(argv=None):
     p.add_argument("--eval_size", type=int, default=100000)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--save", type=str, default="experiments/gu_ffjord")
+    p.add_argument("--resume", type=str, default=None, help="checkpoint written by a previous run (ffjord_checkpoint.pth)")
+    p.add_argument("--max_seconds", type=float, default=0.0, help="stop (with a checkpoint) after this much wall time; 0 = no limit")
+    p.add_argument("--eval_logp_size", type=int, default=20000, help="fresh data points for the E[log p] estimate at log points")
     p.add_argument("--fused", type=int, default=1, help="1: FusedTrainStep (library kernels only, one hipGraph replay per "
                    "iteration); 0: autograd + torch.optim.Adam loop")
     return p.parse_args(argv)
@@ -290,10 +304,43 @@ def main(argv=None):
         fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay)
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=True)
-    t_last = time.time()
-    for itr in range(1, args.niters + 1):
+    start_itr = 0
+    if args.resume:
+        ck = torch.load(args.resume, map_location=device, weights_only=True)
+        model.load_state_dict(ck["model"])
+        start_itr = int(ck["itr"])
+        if fused is not None:
+            fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay)   # parameters were re-assigned: re-alias
+            fused.load_state_dict(ck["optimizer"])
+        else:
+            optimizer.load_state_dict(ck["optimizer"])
+        data = make_gu(args.gu_num, device="cpu", seed=args.seed + start_itr, extend_dim=True)   # a fresh sample stream
+        logger.info("resumed from %s at iteration %d" % (args.resume, start_itr))
+
+    def checkpoint(itr):
+        torch.save({"model": model.state_dict(), "itr": itr,
+                    "optimizer": fused.state_dict() if fused is not None else optimizer.state_dict()},
+                   os.path.join(args.save, "ffjord_checkpoint.pth"))
+        torch.save(model.state_dict(), os.path.join(args.save, "ffjord_state_dict.pth"))
+
+    def mean_log_likelihood():
+        from .parallel_eval import model_log_prob
+        was_training = model.training
+        model.eval()
+        for b in model.chain:
+            b.tile_rows = 16          # evaluation: every 16-row tile controls its own step
+        with torch.no_grad():
+            lp = model_log_prob(model, data.get_sample(args.eval_logp_size).to(device)).mean().item()
+        for b in model.chain:
+            b.tile_rows = 0
+        model.train(was_training)
+        return lp
+
+    t_start = t_last = time.time()
+    itr_last = start_itr
+    for itr in range(start_itr + 1, args.niters + 1):
         x = data.get_sample(args.batch_size).to(device)
-        log_now = itr % args.log_interval == 0 or itr == 1
+        log_now = itr % args.log_interval == 0 or itr == start_itr + 1 or itr == args.niters
         if fused is not None:
             loss = fused(x)
             if log_now:
@@ -306,12 +353,20 @@ def main(argv=None):
             nfe_b = count_nfe(model) - nfe_f
             optimizer.step()
         if log_now:
+            torch.cuda.synchronize()
             now = time.time()
+            per_iter = (now - t_last) / max(1, itr - itr_last)
             wd = evaluate_w_distance(model, data, args.eval_size, device=device)
-            logger.info("iter %06d | loss %.6f | NFE fwd %d bwd %d | %.3f s/iter (incl. logging) | W-distance %.4f"
-                        % (itr, loss.item(), nfe_f, nfe_b, (now - t_last) / max(1, args.log_interval if itr > 1 else 1), wd))
-            torch.save(model.state_dict(), os.path.join(args.save, "ffjord_state_dict.pth"))
-            t_last = time.time()
+            lp = mean_log_likelihood()
+            logger.info("iter %06d | loss %.6f | NFE fwd %d bwd %d | %.3f ms/iter = %.1f iters/s | W-distance %.4f | E[log p] %.4f | wall %.0f s"
+                        % (itr, loss.item(), nfe_f, nfe_b, 1e3 * per_iter, 1.0 / per_iter, wd, lp, now - t_start))
+            checkpoint(itr)
+            t_last, itr_last = time.time(), itr
+        if args.max_seconds and time.time() - t_start > args.max_seconds:
+            torch.cuda.synchronize()
+            checkpoint(itr)
+            logger.info("time limit reached at iteration %d: checkpoint written" % itr)
+            break
     return model
 
 
