@@ -74,16 +74,38 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float xq_sum(float v) {        // sum over the 4 lane quarters (same row j)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+// Cross-lane sums stay on the vector ALU: gfx950's v_permlane{16,32}_swap exchange 16- / 32-lane halves between two
+// registers and DPP moves rotate within a 16-lane row; __shfl_xor compiles to ds_bpermute, an LDS round trip per step.
+__device__ __forceinline__ float xq_sum(float v) {        // sum over the 4 lane quarters (same row j), same in all lanes
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);     // quarters {0,1} and {2,3}
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double xq_sum_f64(double v) {   // sum over the 4 lane quarters, same in all lanes
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+        const auto a = step == 0 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = step == 0 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __longlong_as_double((long long)(((unsigned long long)b[0] << 32) | a[0])) +
+            __longlong_as_double((long long)(((unsigned long long)b[1] << 32) | a[1]));
+    }
     return v;
 }
-__device__ __forceinline__ double row16_sum(double v) {   // sum over the 16 rows of a quarter
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+__device__ __forceinline__ double row16_sum(double v) {   // sum over the 16 rows of a quarter; callers use lane 0's (or one lane's) value
+    v += dpp_mov_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x124>(v);   // row_ror:4
+    v += dpp_mov_f64<0x128>(v);   // row_ror:8
     return v;
 }
 
@@ -384,11 +406,10 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
                 __builtin_amdgcn_s_sleep(1);
             }
             if (!done && lane == 0) red.status = CNF_ERR_SYNC_TIMEOUT;
-            acc += __shfl_xor(acc, 4);
-            acc += __shfl_xor(acc, 8);
-            acc += __shfl_xor(acc, 16);
-            acc += __shfl_xor(acc, 32);
-            s = acc;
+            // lanes with equal (lane & 3) hold partial sums of the same quantity; lanes 0..3 need the totals
+            acc += dpp_mov_f64<0x124>(acc);   // row_ror:4
+            acc += dpp_mov_f64<0x128>(acc);   // row_ror:8
+            s = xq_sum_f64(acc);
         }
         if (lane < 4) red.tot[lane] = s;
     } else {

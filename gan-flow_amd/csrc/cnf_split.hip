@@ -56,15 +56,34 @@ __device__ __forceinline__ void gates_into(const NetLds<D>& n, WS& ws, int lane,
 
 __device__ __forceinline__ float sum4(float a, float b, float c, float d) { return ((a + b) + c) + d; }
 
+// Phase clock for timing experiments (tools/build_variants.sh prof "-DCNF_PROF_CYCLES"): cycles between marks, summed
+// over all evaluations of workgroup 0 / wave 0, printed when the kernel ends.  Compiles to nothing otherwise.
+#ifdef CNF_PROF_CYCLES
+struct Prof {
+    unsigned long long last = 0, acc[16] = {};
+    __device__ __forceinline__ void mark(int i) {
+        const unsigned long long now = clock64();
+        acc[i] += now - last;
+        last = now;
+    }
+};
+#else
+struct Prof {
+    __device__ __forceinline__ void mark(int) {}
+};
+#endif
+
 // ---- forward dynamics, feature-split over the 4 waves ---------------------------------------------------
 template <int D, bool HUTCH, class WS>
 __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, SplitXchg<D>& xc, int lane, int wave, float t,
-                                                const float (&z)[D], const float (&e)[D], float (&f)[D], float& div) {
+                                                const float (&z)[D], const float (&e)[D], float (&f)[D], float& div,
+                                                Prof& pr) {
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     const int q = lane >> 4, j = lane & 15;
     const int fo = 16 * wave + 4 * q;
     gates_into(n, ws, lane, t);
+    pr.mark(1);
     f32x4 act[NS];
     {
         const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[0][0][fo]);
@@ -90,11 +109,13 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
             }
         }
     }
+    pr.mark(2);
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
         __syncthreads();
+        pr.mark(3 + 3 * l);
         f32x4 acc[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -109,6 +130,7 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
 #pragma unroll
                 for (int s = 0; s < NS; ++s) acc[s] = mfma16(a[r], in[s][r], acc[s]);
         }
+        pr.mark(4 + 3 * l);
         const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
         const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
 #pragma unroll
@@ -119,6 +141,7 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
 #pragma unroll
             for (int s = 1; s < NS; ++s) act[s][r] = dg * acc[s][r];
         }
+        pr.mark(5 + 3 * l);
     }
     // layer 4: this wave's 16 features, then across waves through LDS
 #pragma unroll
@@ -137,7 +160,9 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
             xc.part[wave][D + m][j] = pd;
         }
     }
+    pr.mark(9);
     __syncthreads();
+    pr.mark(10);
     div = 0.f;
 #pragma unroll
     for (int m = 0; m < D; ++m) {
@@ -148,6 +173,7 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
         const float dm = g4 * U4;
         div += HUTCH ? dm * e[m] : dm;
     }
+    pr.mark(11);
 }
 
 // ---- forward solve -----------------------------------------------------------------------------------------
@@ -194,12 +220,15 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[C];
 
+    Prof pr;
+    pr.mark(15);
     for (;;) {
         float zz[D], f[D], div, k[C];
         bool restart = false;
 #pragma unroll
         for (int m = 0; m < D; ++m) zz[m] = yi[m];
-        field_fwd_split<D, HUTCH>(net, ws, xc, lane, w, sgn * ti, zz, ee, f, div);
+        pr.mark(0);
+        field_fwd_split<D, HUTCH>(net, ws, xc, lane, w, sgn * ti, zz, ee, f, div, pr);
         ++nfe;
 #pragma unroll
         for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
@@ -254,6 +283,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
             for (int c = 0; c < C; ++c) ws.kst[stage][c][j] = k[c];
             if (stage < 6) {
                 ++stage;
+                pr.mark(12);
             } else {
                 double S[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -269,7 +299,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
                         if (!isfinite(y0[c])) S[2] += 1.0;
                     }
                 }
+                pr.mark(13);
                 if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                pr.mark(14);
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
                 const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
                 const bool accept = (rz <= 1.f) && (rl <= 1.f);
@@ -334,6 +366,13 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
     }
     grid_cleanup(gs, red, tid);
     write_stats_global(a.stats, status, nfe, nacc, nrej, nfe, (float)dt, a.rows, tid);
+#ifdef CNF_PROF_CYCLES
+    if (blockIdx.x == 0 && tid == 0 && nfe > 100) {
+        printf("fwd prof nfe %d cycles/eval:", nfe);
+        for (int i = 0; i < 15; ++i) printf(" [%d] %.0f", i, (double)pr.acc[i] / nfe);
+        printf("\n");
+    }
+#endif
 }
 
 // ============================================================================================================
