@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F_EVAL_D2 = 2 * 8448 + 2 * 2 * (8448 - 2 * 64)   # 50 176 FLOP per sample-eval (d=2, H=64^3, exact div)
+EVAL_LAUNCH_ROWS = 1 << 22   # rows per tile-local launch (the tail of a launch idles CUs: 2^18 -> 2^22 rows is +4 %)
 F_EVAL_D1 = 2 * 8320 + 2 * 1 * (8320 - 1 * 64)   # 33 152 (d=1 fixtures)
 F_EVAL_D2_H256 = 2 * 132096 + 2 * 2 * (132096 - 2 * 256)   # 790 528 per block (d=2, H=256^3, exact divergence)
 PEAK_FP32_MATRIX_TFLOPS = 157.3                  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
@@ -360,8 +361,8 @@ def measure_eval(ctx):
 
     def lp(v):
         parts = []
-        for vc in torch.split(v, 1 << 18):       # one launch per 262 144 rows; tile-local control needs no residency
-            parts.append(parallel_eval.model_log_prob(em, vc, chunk=1 << 18))
+        for vc in torch.split(v, EVAL_LAUNCH_ROWS):   # tile-local control needs no residency: few, large launches
+            parts.append(parallel_eval.model_log_prob(em, vc, chunk=EVAL_LAUNCH_ROWS))
             st = em.chain[0].last_stats["forward"]
             work["row_evals"] += st.row_evals
             work["nfe_max"] = max(work["nfe_max"], st.nfe)
@@ -381,7 +382,7 @@ def measure_eval(ctx):
         del xs
         ctx["barrier"]()
         t0 = time.perf_counter()
-        smp = parallel_eval.sharded_sample(sample_fn, args.eval_rows, 1, rank, world, dev, seed=7, chunk=1 << 18)
+        smp = parallel_eval.sharded_sample(sample_fn, args.eval_rows, 1, rank, world, dev, seed=7, chunk=EVAL_LAUNCH_ROWS)
         ctx["barrier"]()
         sel = ctx["max_over_ranks"](time.perf_counter() - t0)
         smp_mean = smp.double().mean().item()

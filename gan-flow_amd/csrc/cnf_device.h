@@ -134,21 +134,21 @@ struct alignas(16) RedLds {
 };
 
 template <int D>
-__device__ inline void stage_net(NetLds<D>& n, const float* __restrict__ p, int tid) {
+__device__ inline void stage_net(NetLds<D>& n, const float* __restrict__ p, int tid, int nthreads = kThreads) {
     const ParamLayout L = make_layout(D, kH);
     float* img = &n.wimg[0][0][0][0];
-    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += kThreads) {
+    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += nthreads) {
         const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
         const int row = 16 * (tt >> 2) + (lane & 15);
         const int col = 16 * (tt & 3) + 4 * (lane >> 4) + r;
         img[idx] = p[L.w(1 + l) + row * kH + col];
     }
-    for (int idx = tid; idx < D * kH; idx += kThreads) {
+    for (int idx = tid; idx < D * kH; idx += nthreads) {
         const int m = idx / kH, i = idx % kH;
         n.w1[m][i] = p[L.w(0) + i * D + m];
         n.w4[m][i] = p[L.w(3) + m * kH + i];
     }
-    for (int idx = tid; idx < 3 * kH; idx += kThreads) {
+    for (int idx = tid; idx < 3 * kH; idx += nthreads) {
         const int l = idx / kH, i = idx % kH;
         n.vec[l][0][i] = p[L.b(l) + i];
         n.vec[l][1][i] = p[L.hb(l) + i];
@@ -324,11 +324,11 @@ __device__ __forceinline__ void stage_coeffs(int stage, float& alpha, float (&b)
 // hold finite numbers from the start: LDS keeps whatever the previous kernel on the CU left there, and 0 * NaN = NaN.
 // Call before the kernel's first workgroup barrier; `n_ws` = number of per-wave blocks in `wl`.
 template <class WS>
-__device__ __forceinline__ void zero_slopes(WS* wl, int n_ws, int tid) {
+__device__ __forceinline__ void zero_slopes(WS* wl, int n_ws, int tid, int nthreads = kThreads) {
     constexpr int n = (int)(sizeof(wl[0].kst) / sizeof(float));
     for (int i = 0; i < n_ws; ++i) {
         float* k = &wl[i].kst[0][0][0];
-        for (int idx = tid; idx < n; idx += kThreads) k[idx] = 0.f;
+        for (int idx = tid; idx < n; idx += nthreads) k[idx] = 0.f;
     }
 }
 

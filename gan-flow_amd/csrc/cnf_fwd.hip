@@ -134,18 +134,32 @@ __global__ __launch_bounds__(kThreads) void rk4_kernel(SolveArgs a) {
 //   GLOBAL = false: every 16-row tile (one wave) runs its own controller; waves never synchronise
 // The loop is a small state machine around ONE inlined copy of the dynamics.
 // ------------------------------------------------------------------------------------------------
-template <int D, bool HUTCH, bool GLOBAL>
-__global__ __launch_bounds__(kThreads) void dopri5_kernel(SolveArgs a) {
+// Tile-local solves are throughput work: waves of different tiles share a SIMD so that one wave's tanh / gate / Runge-
+// Kutta arithmetic runs in the shadow of another's MFMAs.  Occupancy is what buys that overlap: the register budget
+// is capped for kEvalWaves waves per SIMD (measured on 2^22 rows of the trained stiff field: 2 waves 81, 3 waves 91
+// TFLOP/s at d=1), and a workgroup is NW waves that share one copy of the weight images.
+#ifndef CNF_EVAL_WAVES
+#define CNF_EVAL_WAVES 3
+#endif
+#ifndef CNF_EVAL_NW
+#define CNF_EVAL_NW 4
+#endif
+constexpr int kEvalWaves = CNF_EVAL_WAVES, kEvalNW = CNF_EVAL_NW;
+
+template <int D, bool HUTCH, bool GLOBAL, int NW>
+__global__ __launch_bounds__(NW * 64)
+    __attribute__((amdgpu_waves_per_eu(GLOBAL || D > 2 ? 1 : kEvalWaves, GLOBAL || D > 2 ? 8 : kEvalWaves)))
+    void dopri5_kernel(SolveArgs a) {
     __shared__ NetLds<D> net;
-    __shared__ WaveLds<D> wl[kNW];
+    __shared__ WaveLds<D> wl[NW];
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     constexpr int C = D + 1;
     if (tid == 0) red.status = 0;
-    stage_net(net, a.params, tid);
-    zero_slopes(wl, kNW, tid);
+    stage_net(net, a.params, tid, NW * 64);
+    zero_slopes(wl, NW, tid, NW * 64);
     __syncthreads();
-    const long base = ((long)blockIdx.x * kNW + w) * kRows;
+    const long base = ((long)blockIdx.x * NW + w) * kRows;
     if (!GLOBAL && base >= a.rows) return;
     const long row = base + j;
     const bool counted = row < a.rows && lane < 16;  // this lane's row enters the norms exactly once
@@ -380,9 +394,11 @@ static hipError_t launch_solve_t(const SolveArgs& a, int solver, bool global, hi
     if (solver != CNF_SOLVER_DOPRI5) {
         hipLaunchKernelGGL((rk4_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
     } else if (global) {
-        hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, true>), dim3(grid), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, true, kNW>), dim3(grid), dim3(kThreads), 0, s, a);
     } else {
-        hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
+        constexpr int NW = D > 2 ? kNW : kEvalNW;
+        const int g = (int)((a.rows + NW * kRows - 1) / (NW * kRows));
+        hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, false, NW>), dim3(g), dim3(NW * 64), 0, s, a);
     }
     dbg_timing_end(s);
     return hipGetLastError();

@@ -60,7 +60,7 @@ __device__ __forceinline__ float sum4(float a, float b, float c, float d) { retu
 // over all evaluations of workgroup 0 / wave 0, printed when the kernel ends.  Compiles to nothing otherwise.
 #ifdef CNF_PROF_CYCLES
 struct Prof {
-    unsigned long long last = 0, acc[16] = {};
+    unsigned long long last = 0, acc[20] = {};
     __device__ __forceinline__ void mark(int i) {
         const unsigned long long now = clock64();
         acc[i] += now - last;
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
             t0f = (float)tau;
             stage = 1;
             phase = PH_STAGE;
+            pr.mark(16);
         }
         float alpha_, bc_[6];
         stage_coeffs(stage, alpha_, bc_);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
 #ifdef CNF_PROF_CYCLES
     if (blockIdx.x == 0 && tid == 0 && nfe > 100) {
         printf("fwd prof nfe %d cycles/eval:", nfe);
-        for (int i = 0; i < 15; ++i) printf(" [%d] %.0f", i, (double)pr.acc[i] / nfe);
+        for (int i = 0; i < 17; ++i) printf(" [%d] %.0f", i, (double)pr.acc[i] / nfe);
         printf("\n");
     }
 #endif
