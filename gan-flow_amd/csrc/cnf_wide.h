@@ -24,9 +24,13 @@ struct alignas(16) WideWaveLds {
     float kst[7][C][kRows];
 };
 
-template <int D, int NS>
+// NB = 2: the two hidden layers' inputs in separate buffers (no barrier between a layer's reads and the next layer's
+// writes; latency-bound batch-global solves, one workgroup per CU anyway).  NB = 1: one buffer and one more barrier
+// per evaluation, which brings a workgroup under 80 KB so that TWO are resident per CU (tile-local throughput solves).
+template <int D, int NS, int NB = 2>
 struct alignas(16) WideXchg {
-    float xb[2][NS][kWT][64][4];
+    static constexpr int kBuffers = NB;
+    float xb[NB][NS][kWT][64][4];
     float part[kNW][2 * D][kRows];
 };
 

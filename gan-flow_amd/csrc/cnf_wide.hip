@@ -17,8 +17,8 @@
 namespace cnf {
 
 // ---- forward dynamics -----------------------------------------------------------------------------------------
-template <int D, bool HUTCH, class WS>
-__device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, WideXchg<D, (HUTCH ? 1 : D) + 1>& xc,
+template <int D, bool HUTCH, class WS, class XC>
+__device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, XC& xc,
                                                const float* __restrict__ params, int lane, int wave, float t,
                                                const float (&z)[D], const float (&e)[D], float (&f)[D], float& div) {
     constexpr int NT = HUTCH ? 1 : D;
@@ -71,10 +71,13 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, W
     // layers 2, 3: 256 x 256 on the matrix cores, weights streamed from the (L2-resident) parameter vector
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
+        constexpr int NB = XC::kBuffers;
+        const int lb = l % NB;
+        if (NB == 1 && l == 1) __syncthreads();   // every wave is past its reads of layer 2's input
 #pragma unroll
         for (int T = 0; T < kWTW; ++T)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][kWTW * wave + T][lane][0]) = act[T][s];
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[lb][s][kWTW * wave + T][lane][0]) = act[T][s];
         // row 64 wave + 16 T + j of W, columns 16 Ti + 4 q .. + 3
         const float* wrow = params + make_layout(D, kWH).w(1 + l) + (size_t)(kWF * wave + j) * kWH + 4 * q;
         f32x4 wnext[kWTW];
@@ -96,7 +99,7 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, W
             for (int T = 0; T < kWTW; ++T) wnext[T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * Tn);
             f32x4 in[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
+            for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[lb][s][Ti][lane][0]);
 #pragma unroll
             for (int T = 0; T < kWTW; ++T)
 #pragma unroll
@@ -182,12 +185,12 @@ __global__ __launch_bounds__(kThreads) void wide_field_kernel(const float* __res
 
 // ---- fixed-grid RK4 (3/8 rule), as rk4_kernel in cnf_fwd.hip ---------------------------------------------------
 template <int D, bool HUTCH>
-__global__ __launch_bounds__(kThreads) void wide_rk4_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void wide_rk4_kernel(SolveArgs a) {
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = D + 1;
     __shared__ WideNetLds<D> net;
     __shared__ WideWaveLds<C> wl[kNW];
-    __shared__ WideXchg<D, NS> xc;
+    __shared__ WideXchg<D, NS, 1> xc;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     wide_stage_net(net, a.params, tid);
     __syncthreads();
@@ -266,13 +269,16 @@ __global__ __launch_bounds__(kThreads) void wide_rk4_kernel(SolveArgs a) {
 }
 
 // ---- dopri5: the controller of dopri5_split_kernel (cnf_split.hip); GLOBAL = false: this tile is the control group
+// Tile-local: two workgroups per CU (single exchange buffer, registers capped at 256), so that one workgroup's
+// barriers, tanh and weight-stream latency are covered by the other's MFMAs.
 template <int D, bool HUTCH, bool GLOBAL>
-__global__ __launch_bounds__(kThreads) void wide_dopri5_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GLOBAL ? 1 : 2, GLOBAL ? 8 : 2)))
+void wide_dopri5_kernel(SolveArgs a) {
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = D + 1;
     __shared__ WideNetLds<D> net;
     __shared__ WideWaveLds<C> wl[kNW];
-    __shared__ WideXchg<D, NS> xc;
+    __shared__ WideXchg<D, NS, GLOBAL ? 2 : 1> xc;
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
