@@ -96,11 +96,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the CNF path is a HIP kernel with no CPU fallback")
-    dev = torch.device("cuda", local)
+    # BENCH_DIST_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then share
+    # devices; RCCL refuses that).  The driver's runs use the default: nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local if backend == "nccl" else local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gan_flow_amd import _native, gu_ffjord, parallel_eval
     from gan_flow_amd.gu import make_gu

@@ -39,11 +39,24 @@ __global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict
     }
 }
 
+// Tile-local and fixed-grid solves are throughput work: waves of different tiles share a SIMD so that one wave's tanh / gate / Runge-
+// Kutta arithmetic runs in the shadow of another's MFMAs.  Occupancy is what buys that overlap: the register budget
+// is capped for kEvalWaves waves per SIMD (measured on 2^22 rows of the trained stiff field: 2 waves 81, 3 waves 91
+// TFLOP/s at d=1), and a workgroup is NW waves that share one copy of the weight images.
+#ifndef CNF_EVAL_WAVES
+#define CNF_EVAL_WAVES 3
+#endif
+#ifndef CNF_EVAL_NW
+#define CNF_EVAL_NW 4
+#endif
+constexpr int kEvalWaves = CNF_EVAL_WAVES, kEvalNW = CNF_EVAL_NW;
+
 // ------------------------------------------------------------------------------------------------
 // fixed-grid RK4, 3/8 rule (Appendix B.6).  No cross-row coupling: waves are independent.
 // ------------------------------------------------------------------------------------------------
 template <int D, bool HUTCH>
-__global__ __launch_bounds__(kThreads) void rk4_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D > 2 ? 1 : kEvalWaves, D > 2 ? 8 : kEvalWaves)))
+void rk4_kernel(SolveArgs a) {
     __shared__ NetLds<D> net;
     __shared__ WaveLds<D> wl[kNW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
@@ -134,18 +147,6 @@ __global__ __launch_bounds__(kThreads) void rk4_kernel(SolveArgs a) {
 //   GLOBAL = false: every 16-row tile (one wave) runs its own controller; waves never synchronise
 // The loop is a small state machine around ONE inlined copy of the dynamics.
 // ------------------------------------------------------------------------------------------------
-// Tile-local solves are throughput work: waves of different tiles share a SIMD so that one wave's tanh / gate / Runge-
-// Kutta arithmetic runs in the shadow of another's MFMAs.  Occupancy is what buys that overlap: the register budget
-// is capped for kEvalWaves waves per SIMD (measured on 2^22 rows of the trained stiff field: 2 waves 81, 3 waves 91
-// TFLOP/s at d=1), and a workgroup is NW waves that share one copy of the weight images.
-#ifndef CNF_EVAL_WAVES
-#define CNF_EVAL_WAVES 3
-#endif
-#ifndef CNF_EVAL_NW
-#define CNF_EVAL_NW 4
-#endif
-constexpr int kEvalWaves = CNF_EVAL_WAVES, kEvalNW = CNF_EVAL_NW;
-
 template <int D, bool HUTCH, bool GLOBAL, int NW>
 __global__ __launch_bounds__(NW * 64)
     __attribute__((amdgpu_waves_per_eu(GLOBAL || D > 2 ? 1 : kEvalWaves, GLOBAL || D > 2 ? 8 : kEvalWaves)))

@@ -14,6 +14,10 @@
 // width needs 2 x 256 x 256 gradient accumulators per workgroup, which do not fit in registers: not built yet.
 #include "cnf_wide.h"
 
+#ifndef CNF_WIDE_PF
+#define CNF_WIDE_PF 1
+#endif
+
 namespace cnf {
 
 // ---- forward dynamics -----------------------------------------------------------------------------------------
@@ -80,23 +84,27 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
             for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[lb][s][kWTW * wave + T][lane][0]) = act[T][s];
         // row 64 wave + 16 T + j of W, columns 16 Ti + 4 q .. + 3
         const float* wrow = params + make_layout(D, kWH).w(1 + l) + (size_t)(kWF * wave + j) * kWH + 4 * q;
-        f32x4 wnext[kWTW];
+        // ring of kPF + 1 register buffers: the blocks of input tiles Ti + 1 .. Ti + kPF are in flight while tile Ti
+        // feeds the matrix pipe (one tile = 48 MFMAs ~ 1.5k cycles at NS = 3; an L2 round trip is of that order)
+        constexpr int kPF = CNF_WIDE_PF, kRing = kPF + 1;
+        f32x4 wbuf[kRing][kWTW];
 #pragma unroll
-        for (int T = 0; T < kWTW; ++T) wnext[T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH);   // input tile 0, issued before the barrier
+        for (int p = 0; p < kPF; ++p)
+#pragma unroll
+            for (int T = 0; T < kWTW; ++T) wbuf[p][T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * p);   // issued before the barrier
         __syncthreads();
         f32x4 acc[kWTW][NS];
 #pragma unroll
         for (int T = 0; T < kWTW; ++T)
 #pragma unroll
             for (int s = 0; s < NS; ++s) acc[T][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        static_assert(4 % kRing == 0, "ring slots must be compile-time after unrolling by 4");
 #pragma unroll 4
         for (int Ti = 0; Ti < kWT; ++Ti) {
-            f32x4 wcur[kWTW];
+            const int Tn = Ti + kPF < kWT ? Ti + kPF : kWT - 1;   // past the end: a redundant load instead of a branch
 #pragma unroll
-            for (int T = 0; T < kWTW; ++T) wcur[T] = wnext[T];
-            const int Tn = Ti + 1 < kWT ? Ti + 1 : Ti;
-#pragma unroll
-            for (int T = 0; T < kWTW; ++T) wnext[T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * Tn);
+            for (int T = 0; T < kWTW; ++T)
+                wbuf[(Ti + kPF) % kRing][T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * Tn);
             f32x4 in[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[lb][s][Ti][lane][0]);
@@ -105,7 +113,7 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma16(wcur[T][r], in[s][r], acc[T][s]);
+                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma16(wbuf[Ti % kRing][T][r], in[s][r], acc[T][s]);
         }
 #pragma unroll
         for (int T = 0; T < kWTW; ++T) {
