@@ -48,8 +48,8 @@ def parse():
     p.add_argument("--mode", type=str, default="fused", choices=["fused", "graph", "eager"],
                    help="fused: gu_ffjord.FusedTrainStep (solves + cnf_nll_loss + cnf_adam_step, one hipGraph replay per "
                         "iteration); graph: autograd + torch.optim.Adam loop captured as one hipGraph; eager: that loop, launched eagerly")
-    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,wide,cpu",
-                   help="comma list of the additional measurements to run: roofline, late, eval, d16, wide, cpu ('' = none)")
+    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,wide,pair,cpu",
+                   help="comma list of the additional measurements to run: roofline, late, eval, d16, wide, pair, cpu ('' = none)")
     return p.parse_args()
 
 
@@ -195,6 +195,8 @@ def main():
         out["d16_hutchinson"] = measure_d16(ctx)
     if "wide" in extras:
         out["h256_4blocks"] = measure_wide(ctx)
+    if "pair" in extras:
+        out["two_trials_per_gpu"] = measure_pair(ctx)
     if "cpu" in extras and rank == 0 and world == 1 and args.cpu_iters > 0:
         out["cpu_baseline"] = measure_cpu(ctx)
 
@@ -291,6 +293,41 @@ def measure_d16(ctx):
             "workload": "FFJORD CNF on the synthetic d=16 8-component Gaussian mixture, B=%d, ODEnet 16-64-64-64-16, "
                         "Hutchinson divergence (Gaussian probe, fresh per iteration), dopri5 1e-5, adjoint, Adam; "
                         "seed 1+rank per GPU" % args.batch}
+
+
+def measure_pair(ctx):
+    """Two independent trials of the headline workload per GPU (gu_ffjord.ConcurrentTrials): a B=2048 solve occupies 128
+    of the 256 compute units, so a sweep can run two trials in the time of one.  Reported beside the headline, never as
+    it: the headline is ONE training run."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    args, world, rank, dev = ctx["args"], ctx["world"], ctx["rank"], ctx["dev"]
+    out = {}
+    for name, late, steps in (("early", False, args.steps), ("late", True, args.late_steps)):
+        trials, feeds = [], []
+        for k in range(2):
+            data = make_gu(8, device="cpu", seed=101 + 2 * rank + k, extend_dim=True)
+            xs = [data.get_sample(args.batch).to(dev) for _ in range(args.warmup + steps)]
+            torch.manual_seed(101 + 2 * rank + k)
+            model = gu_ffjord.build_model(2)
+            if late:
+                model = embed_trained_multimodal(model)
+            model = model.to(dev).train()
+            trials.append(gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True,
+                                                   warmup_batches=xs[:1 if late else max(1, args.warmup)]))
+            feeds.append(xs[args.warmup:])
+        both = gu_ffjord.ConcurrentTrials(trials)
+        ctx["barrier"]()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            both([feeds[0][i], feeds[1][i]])
+        ctx["barrier"]()
+        el = ctx["max_over_ranks"](time.perf_counter() - t0)
+        nfe = both.check()
+        out[name] = {"value": round(2 * world * steps / el, 2), "unit": "iters/s (sum of both trials)",
+                     "ms_per_step_pair": round(1e3 * el / steps, 4), "nfe": [list(v) for v in nfe]}
+    out["workload"] = "two concurrent trials of the headline workload per GPU, each on its own stream (one hipGraph replay per trial and iteration)"
+    return out
 
 
 def measure_wide(ctx):

@@ -251,6 +251,43 @@ class FusedTrainStep:
             s.copy_(torch.tensor([int(n), 0], dtype=torch.int32))
 
 
+class ConcurrentTrials:
+    """Several independent trainings (hyper-parameter sweeps, seeds: how the reference's Ray Tune driver uses gu_maf) on
+    ONE GPU at the same time.  A batch-global solve at B=2048 is 128 workgroups, i.e. half of an MI355X's 256 compute
+    units, and its time is a dependent chain, not throughput: two trials on two streams finish in the time of one.
+
+    `trials`: FusedTrainStep objects built with graph=True.  Every trial's iteration is replayed on a stream of its own.
+    The solves synchronise their workgroups across the grid, so ALL workgroups of ALL concurrently running solves must
+    be resident: the constructor checks sum(ceil(B_i / 16)) <= compute units.  (Should residency fail anyway, e.g. with
+    other work on the GPU, the spins are bounded and .check() raises a sync-timeout CnfError: nothing hangs.)"""
+
+    def __init__(self, trials):
+        self.trials = list(trials)
+        if not self.trials or any(t.graph is None for t in self.trials):
+            raise ValueError("ConcurrentTrials needs FusedTrainStep objects built with graph=True")
+        dev = self.trials[0].static_x.device
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        need = sum((t.static_x.shape[0] + 15) // 16 for t in self.trials)
+        if need > cus:
+            raise ValueError("%d concurrently resident workgroups needed, the device has %d compute units" % (need, cus))
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.trials]
+
+    def __call__(self, batches):
+        """One iteration of every trial; `batches[i]` feeds trial i.  Returns the trials' (device) loss tensors."""
+        cur = torch.cuda.current_stream()
+        losses = []
+        for t, st, x in zip(self.trials, self.streams, batches):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                losses.append(t(x))
+        for st in self.streams:
+            cur.wait_stream(st)
+        return losses
+
+    def check(self):
+        return [t.check() for t in self.trials]
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser("FFJORD CNF on the Gaussian-uniform mixture (MI355X HIP path)")
     p.add_argument("--gu_num", type=int, default=8, help="1 = unimodal, 8 = multimodal")

@@ -149,3 +149,35 @@ def test_fused_train_step_d16_hutchinson_gmm(graph):
     e2 = model.chain[0].odefunc.odefunc._e
     if not graph:
         assert e1 is not e2 and not torch.equal(e1, e2)       # a new probe per iteration
+
+
+def test_concurrent_trials_match_sequential():
+    """Two trainings replayed on two streams of one GPU (gu_ffjord.ConcurrentTrials) follow exactly the trajectories they
+    follow alone: the kernels are deterministic and share nothing but the device."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    datas = [make_gu(8, seed=11), make_gu(8, seed=12)]
+    batches = [[d.get_sample(2048).to(DEV) for _ in range(10)] for d in datas]
+
+    def build(seed, bs):
+        torch.manual_seed(seed)
+        model = gu_ffjord.build_model(2).to(DEV).train()
+        return model, gu_ffjord.FusedTrainStep(model, bs[0], lr=1e-3, weight_decay=1e-5, graph=True)
+
+    alone = []
+    for k in range(2):
+        _, step = build(20 + k, batches[k])
+        alone.append([step(x).item() for x in batches[k]])
+        step.check()
+    pairs = [build(20 + k, batches[k]) for k in range(2)]
+    both = gu_ffjord.ConcurrentTrials([p[1] for p in pairs])
+    together = [[], []]
+    for i in range(10):
+        la, lb = both([batches[0][i], batches[1][i]])
+        torch.cuda.synchronize()
+        together[0].append(la.item())
+        together[1].append(lb.item())
+    both.check()
+    assert together == alone
+    with pytest.raises(ValueError):
+        gu_ffjord.ConcurrentTrials([p[1] for p in pairs] * 2)        # 4 x 128 workgroups do not fit 256 compute units
