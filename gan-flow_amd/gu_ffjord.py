@@ -17,12 +17,12 @@ from .util import count_parameters, get_logger, makedirs, w_distance
 
 
 def build_model(dim=2, dims=(64, 64, 64), num_blocks=1, time_length=0.5, train_T=True, divergence_fn="brute_force",
-                solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False):
+                solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False, layer_type="concatsquash"):
     """`num_blocks` CNF blocks over a dim -> dims -> dim concatsquash/tanh ODEnet: the architecture stored in the
-    reference's checkpoints."""
+    reference's checkpoints.  Other `layer_type`s: see ODEnet."""
     blocks = []
     for _ in range(num_blocks):
-        net = ODEnet(tuple(dims), (dim,), strides=None, conv=False, layer_type="concatsquash", nonlinearity="tanh")
+        net = ODEnet(tuple(dims), (dim,), strides=None, conv=False, layer_type=layer_type, nonlinearity="tanh")
         fn = ODEfunc(net, divergence_fn=divergence_fn, residual=False, rademacher=rademacher)
         blocks.append(CNF(fn, T=time_length, train_T=train_T, regularization_fns=(), solver=solver, atol=atol, rtol=rtol))
     return SequentialFlow(blocks)
@@ -299,6 +299,8 @@ def parse_args(argv=None):
     p.add_argument("--weight_decay", type=float, default=1e-5)
     p.add_argument("--dims", type=str, default="64-64-64")
     p.add_argument("--num_blocks", type=int, default=1)
+    p.add_argument("--layer_type", type=str, default="concatsquash",
+                   choices=["ignore", "concat", "concatcoord", "concat_v2", "squash", "concatsquash"])
     p.add_argument("--time_length", type=float, default=0.5)
     p.add_argument("--train_T", type=eval, default=True, choices=[True, False])
     p.add_argument("--divergence_fn", type=str, default="brute_force", choices=["brute_force", "approximate"])
@@ -329,7 +331,10 @@ def main(argv=None):
     data = make_gu(args.gu_num, device="cpu", seed=args.seed, extend_dim=True)
     torch.manual_seed(args.seed)
     model = build_model(2, tuple(int(d) for d in args.dims.split("-")), args.num_blocks, args.time_length, args.train_T,
-                        args.divergence_fn, args.solver, args.atol, args.rtol).to(device)
+                        args.divergence_fn, args.solver, args.atol, args.rtol, layer_type=args.layer_type).to(device)
+    if args.layer_type != "concatsquash" and args.fused:
+        logger.info("layer_type %s: autograd + torch.optim.Adam loop (FusedTrainStep updates concatsquash nets only)" % args.layer_type)
+        args.fused = 0
     if args.step_size:
         for block in model.chain:
             block.solver_options["step_size"] = args.step_size

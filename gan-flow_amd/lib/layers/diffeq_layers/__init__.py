@@ -1,1 +1,2 @@
-from .basic import ConcatSquashLinear  # noqa: F401
+from .basic import (ConcatLinear, ConcatLinear_v2, ConcatSquashLinear, IgnoreLinear, LAYER_TYPES,  # noqa: F401
+                    SquashLinear)

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from ... import _native
-from .diffeq_layers.basic import ConcatSquashLinear
+from .diffeq_layers.basic import LAYER_TYPES, ConcatSquashLinear
 
 
 def divergence_bf(dx, y, **unused_kwargs):
@@ -21,32 +21,40 @@ def divergence_approx(f, y, e=None):
 
 
 class ODEnet(nn.Module):
-    """dim -> hidden_dims -> dim stack of ConcatSquashLinear layers with tanh between (not after) them."""
+    """dim -> hidden_dims -> dim stack of time-conditioned linear layers with tanh between (not after) them.
+    layer_type: 'concatsquash' (the reference's runs and checkpoints) or one of its special cases 'ignore', 'concat',
+    'concatcoord', 'concat_v2', 'squash' (diffeq_layers/basic.py); 'hyper' and 'blend' have time-dependent weight
+    matrices and are not built."""
 
     def __init__(self, hidden_dims, input_shape, strides=None, conv=False, layer_type="concatsquash",
                  nonlinearity="tanh", num_squeeze=0):
         super().__init__()
-        if conv or layer_type != "concatsquash" or nonlinearity != "tanh" or num_squeeze != 0:
-            raise NotImplementedError("the HIP path is built for the reference's configuration: "
-                                      "layer_type='concatsquash', nonlinearity='tanh', no conv/squeeze")
+        if conv or layer_type not in LAYER_TYPES or nonlinearity != "tanh" or num_squeeze != 0:
+            raise NotImplementedError("the HIP path is built for layer_type in %s, nonlinearity='tanh', no conv/squeeze "
+                                      "(got layer_type=%r, nonlinearity=%r)" % (sorted(LAYER_TYPES), layer_type, nonlinearity))
         self.num_squeeze = num_squeeze
+        self.layer_type = layer_type
         dims = (int(input_shape[0]),) + tuple(int(h) for h in hidden_dims) + (int(input_shape[0]),)
-        self.layers = nn.ModuleList(ConcatSquashLinear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.layers = nn.ModuleList(LAYER_TYPES[layer_type](a, b) for a, b in zip(dims[:-1], dims[1:]))
         self.activation_fns = nn.ModuleList(nn.Tanh() for _ in range(len(dims) - 2))
 
     @property
     def dims(self):
-        return (self.layers[0]._layer.in_features,) + tuple(l._layer.out_features for l in self.layers)
+        return (self.layers[0].dim_in,) + tuple(l.dim_out for l in self.layers)
 
     def flat_parameters(self):
-        """The parameter vector in the order include/cnf_hip.h documents (== self.parameters() order)."""
-        return torch.cat([p.reshape(-1) for p in self.parameters()])
+        """The parameter vector in the order include/cnf_hip.h documents: per layer W, b, w_hb, w_g, b_g (for
+        concatsquash that is self.parameters() order; the other layer types fill in constants, see basic.py)."""
+        return torch.cat([p.reshape(-1) for layer in self.layers for p in layer.kernel_slices()])
 
     def flatten_parameters(self):
         """Move the parameters into ONE contiguous buffer laid out as the kernels read it and make every
         nn.Parameter a view of its slice (names, shapes and state_dict are unchanged).  Returns the buffer: an update
         written to it (gu_ffjord.FusedTrainStep) is an update of the module's parameters.  `.to()` / `.cuda()` /
         load_state_dict(assign=True) re-allocate parameters: call again afterwards (flat_is_current() tells)."""
+        if self.layer_type != "concatsquash":
+            raise NotImplementedError("flatten_parameters (and FusedTrainStep) need layer_type='concatsquash': the other "
+                                      "layer types present constants to the kernels that an in-place optimizer must not touch")
         ps = list(self.parameters())
         flat = torch.cat([p.detach().reshape(-1) for p in ps])
         off = 0

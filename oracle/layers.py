@@ -28,6 +28,49 @@ class ConcatSquashLinear(nn.Module):
         return self._layer(x) * torch.sigmoid(self._hyper_gate(tt)) + self._hyper_bias(tt)
 
 
+# The other layers of ffjord/lib/layers/diffeq_layers/basic.py that are special cases of the concatsquash form
+# (SURVEY.md section 8f row N4).  UPSTREAM-RECALL: the submodule is not vendored and no checkpoint uses them.
+class IgnoreLinear(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self._layer = nn.Linear(dim_in, dim_out)
+
+    def forward(self, t, x):
+        return self._layer(x)
+
+
+class ConcatLinear(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self._layer = nn.Linear(dim_in + 1, dim_out)
+
+    def forward(self, t, x):
+        tt = torch.ones_like(x[:, :1]) * t
+        return self._layer(torch.cat([tt, x], 1))
+
+
+class ConcatLinear_v2(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self._layer = nn.Linear(dim_in, dim_out)
+        self._hyper_bias = nn.Linear(1, dim_out, bias=False)
+
+    def forward(self, t, x):
+        return self._layer(x) + self._hyper_bias(t.reshape(1, 1))
+
+
+class SquashLinear(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self._layer = nn.Linear(dim_in, dim_out)
+        self._hyper = nn.Linear(1, dim_out)
+
+    def forward(self, t, x):
+        return self._layer(x) * torch.sigmoid(self._hyper(t.reshape(1, 1)))
+
+
+_LAYERS = {"ignore": IgnoreLinear, "concat": ConcatLinear, "concatcoord": ConcatLinear, "concat_v2": ConcatLinear_v2,
+           "squash": SquashLinear, "concatsquash": ConcatSquashLinear}
 _ACTIVATIONS = {"tanh": nn.Tanh, "softplus": nn.Softplus, "relu": nn.ReLU, "elu": nn.ELU}
 
 
@@ -37,10 +80,10 @@ class ODEnet(nn.Module):
     def __init__(self, hidden_dims, input_shape, strides=None, conv=False, layer_type="concatsquash",
                  nonlinearity="tanh", num_squeeze=0):
         super().__init__()
-        assert not conv and layer_type == "concatsquash", "oracle restates the configuration the checkpoints pin"
+        assert not conv and layer_type in _LAYERS, "oracle restates the fully connected time-conditioned layers only"
         self.num_squeeze = num_squeeze
         dims = (input_shape[0],) + tuple(hidden_dims) + (input_shape[0],)
-        self.layers = nn.ModuleList(ConcatSquashLinear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.layers = nn.ModuleList(_LAYERS[layer_type](a, b) for a, b in zip(dims[:-1], dims[1:]))
         self.activation_fns = nn.ModuleList(_ACTIVATIONS[nonlinearity]() for _ in range(len(dims) - 2))
 
     def forward(self, t, y):
@@ -228,11 +271,12 @@ def standard_normal_logprob(z):
 
 
 def build_cnf(dim, hidden_dims=(64, 64, 64), num_blocks=1, T=0.5, train_T=True, divergence_fn="brute_force",
-              solver="dopri5", atol=1e-5, rtol=1e-5, nonlinearity="tanh", rademacher=False, residual=False):
+              solver="dopri5", atol=1e-5, rtol=1e-5, nonlinearity="tanh", rademacher=False, residual=False,
+              layer_type="concatsquash"):
     """The model the reference's checkpoints hold: `num_blocks` CNF blocks, concatsquash/tanh ODEnet."""
     blocks = []
     for _ in range(num_blocks):
-        net = ODEnet(tuple(hidden_dims), (dim,), strides=None, conv=False, layer_type="concatsquash",
+        net = ODEnet(tuple(hidden_dims), (dim,), strides=None, conv=False, layer_type=layer_type,
                      nonlinearity=nonlinearity)
         fn = ODEfunc(net, divergence_fn=divergence_fn, residual=residual, rademacher=rademacher)
         blocks.append(CNF(fn, T=T, train_T=train_T, regularization_fns=(), solver=solver, atol=atol, rtol=rtol))

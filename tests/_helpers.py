@@ -42,7 +42,7 @@ def oracle_random_model(dim, seed=1, divergence_fn="brute_force", scale=1.0, **k
 def product_like(oracle_model, device, divergence_fn="brute_force", **kw):
     """The product model (HIP path) carrying the oracle model's weights."""
     from gan_flow_amd import gu_ffjord
-    dim = oracle_model.chain[0].odefunc.odefunc.diffeq.layers[0]._layer.in_features
+    dim = oracle_model.chain[0].odefunc.odefunc.diffeq.layers[-1]._layer.out_features
     blocks = len(oracle_model.chain)
     m = gu_ffjord.build_model(dim, num_blocks=blocks, divergence_fn=divergence_fn, **kw)
     m.load_state_dict({k: v.float() for k, v in oracle_model.state_dict().items()})

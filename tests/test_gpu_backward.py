@@ -171,6 +171,31 @@ def test_module_training_step_fills_parameter_grads():
     assert mp.chain[0].sqrt_end_time.grad is None       # the end time is detached, as in the reference
 
 
+@pytest.mark.parametrize("layer_type", ["ignore", "concat", "concat_v2", "squash"])
+def test_other_layer_types_run_on_the_same_kernels(layer_type):
+    """the diffeq layers that are special cases of concatsquash reach the kernels through
+    kernel_slices() (constants for the absent gate / time term); loss, step counts and the gradients of the layer's OWN
+    parameters match the oracle's autograd through its adjoint.  (Layer definitions are UPSTREAM-RECALL: parity unpinned.)"""
+    from gan_flow_amd import gu_ffjord
+    mo = oracle_random_model(2, seed=13, scale=1.5, layer_type=layer_type)
+    mo.train()
+    mp = product_like(mo, DEV, layer_type=layer_type)
+    mp.train()
+    assert [k for k, _ in mp.named_parameters()] == [k for k, _ in mo.named_parameters()]
+    x = torch.randn(512, 2, generator=torch.Generator().manual_seed(2))
+    loss_ref, z_ref, dl_ref, gx_ref, gp_ref, st_ref = _oracle_train_grads(mo, x)
+    xp = x.to(DEV).requires_grad_(True)
+    loss = gu_ffjord.compute_loss(mp, xp)
+    loss.backward()
+    gp = torch.cat([p.grad.reshape(-1) for p in mp.chain[0].odefunc.odefunc.diffeq.parameters()])
+    assert abs(loss.item() - loss_ref) < 1e-4
+    assert gu_ffjord.count_nfe(mp) == mo.chain[0].num_evals()
+    assert gp.numel() == gp_ref.numel()
+    assert rel_err(gp, gp_ref) < 2e-4 and rel_err(xp.grad, gx_ref) < 2e-4
+    with pytest.raises(NotImplementedError):
+        gu_ffjord.FusedTrainStep(mp, xp.detach(), graph=False)
+
+
 def test_short_training_run_reduces_loss():
     """Ten Adam steps of the real driver loop on gu_num=8 data lower the negative log-likelihood."""
     from gan_flow_amd import gu_ffjord

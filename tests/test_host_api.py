@@ -169,3 +169,30 @@ def test_legacy_checkpoint_reader_on_reference_files(which):
     blk = m.chain[0]
     assert (blk.solver, blk.atol, blk.rtol, blk.test_solver) == ("dopri5", 1e-5, 1e-5, "dopri5")
     assert abs(float(blk.sqrt_end_time.detach()) ** 2 - 0.5) < 1e-6
+
+
+@pytest.mark.parametrize("layer_type", ["ignore", "concat", "concatcoord", "concat_v2", "squash", "concatsquash"])
+def test_layer_types_present_themselves_as_concatsquash(layer_type):
+    """kernel_slices() of every supported diffeq layer, put through the formula the kernels evaluate
+    ((W x + b) * sigmoid(w_g t + b_g) + w_hb t), reproduces the layer's own forward; state_dict keys match the oracle's."""
+    import oracle
+    from gan_flow_amd.lib.layers.odefunc import ODEnet
+    torch.manual_seed(3)
+    net = ODEnet((64, 64, 64), (2,), layer_type=layer_type)
+    ref = oracle.layers.ODEnet((64, 64, 64), (2,), layer_type=layer_type)
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+    assert net.dims == (2, 64, 64, 64, 2)
+    flat = net.flat_parameters()
+    assert flat.numel() == 9224                       # the kernels' layout does not depend on the layer type
+    x, t = torch.randn(7, 2), torch.tensor(0.37)
+    h = x
+    for layer in net.layers:
+        w, b, hb, wg, bg = layer.kernel_slices()
+        mine = (h @ w.t() + b) * torch.sigmoid(wg.reshape(-1) * t + bg) + hb.reshape(-1) * t
+        assert torch.allclose(mine, layer(t, h), rtol=0, atol=1e-6)
+        h = torch.tanh(mine)
+    if layer_type != "concatsquash":
+        with pytest.raises(NotImplementedError):
+            net.flatten_parameters()
+    with pytest.raises(NotImplementedError):
+        ODEnet((64, 64, 64), (2,), layer_type="blend")
