@@ -240,7 +240,7 @@ def measure_roofline(ctx):
     flops = args.batch * st.nfe * 3 * F_EVAL_D2
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None   # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/): not measurable in-process
-    tpath = os.path.join(ROOT, "profiles", "r01d_bwd_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01e_bwd_traffic.json")
     if os.path.exists(tpath) and args.batch == 2048:
         with open(tpath) as fh:
             traffic = json.load(fh)["hbm_bytes_per_launch"]
