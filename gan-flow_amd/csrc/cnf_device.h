@@ -359,9 +359,11 @@ struct GridSync {
 constexpr unsigned kSpinLimit = 1u << 24;
 
 // returns false on timeout (status set in red.status).  All threads of the workgroup must call it.
+// ALLQ: all four lane quarters of a wave carry contributions (cnf_split16.hip), not just quarter 0.
+template <bool ALLQ = false>
 __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], int w, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = row16_sum(v[i]);
+    for (int i = 0; i < 4; ++i) v[i] = ALLQ ? xq_sum_f64(row16_sum(v[i])) : row16_sum(v[i]);
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) red.part[w][i] = v[i];

@@ -32,6 +32,8 @@ struct SolveArgs {
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
                         float* f_out, float* nd_out, hipStream_t s);
 hipError_t launch_solve_fwd(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
+// d = 16, Hutchinson, rows <= 4096, x / e / z_out / params 16-byte aligned (cnf_split16.hip)
+hipError_t launch_split16_fwd(const SolveArgs& a, hipStream_t s);
 
 // diagnostics (cnf_debug_kernel_timing): when enabled, record a HIP event on `s` right before / after a solve kernel
 void dbg_timing_begin(hipStream_t s);

@@ -1184,7 +1184,11 @@ hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
     if (D == 1 && !hutch) return split_fwd_t<1, false>(a, s);
     if (D == 2 && !hutch) return split_fwd_t<2, false>(a, s);
     if (D == 2 && hutch) return split_fwd_t<2, true>(a, s);
-    if (D == 16 && hutch) return split_fwd_t<16, true>(a, s);
+    if (D == 16 && hutch) {
+        // state spread over the lane quarters (cnf_split16.hip) when its 16-byte accesses are aligned
+        const uintptr_t al = (uintptr_t)a.x | (uintptr_t)a.e | (uintptr_t)a.z_out | (uintptr_t)a.params;
+        return (al & 15) == 0 ? launch_split16_fwd(a, s) : split_fwd_t<16, true>(a, s);
+    }
     return hipErrorNotSupported;
 }
 
