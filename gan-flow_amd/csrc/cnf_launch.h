@@ -34,6 +34,7 @@ hipError_t launch_field(int D, bool hutch, const float* params, float t, const f
 hipError_t launch_solve_fwd(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
 // d = 16, Hutchinson, rows <= 4096, x / e / z_out / params 16-byte aligned (cnf_split16.hip)
 hipError_t launch_split16_fwd(const SolveArgs& a, hipStream_t s);
+hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s);   // + grad_z1 / grad_x aligned
 
 // diagnostics (cnf_debug_kernel_timing): when enabled, record a HIP event on `s` right before / after a solve kernel
 void dbg_timing_begin(hipStream_t s);

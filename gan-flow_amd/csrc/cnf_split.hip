@@ -12,7 +12,7 @@
 // Runge-Kutta state (identical arithmetic, bit-identical results), so the controller logic is unchanged.
 // Used when rows <= 16 * 256 (every workgroup resident for the grid-wide reductions); larger batch-global solves
 // fall back to the one-wave-per-tile kernels.
-#include "cnf_launch.h"
+#include "cnf_split.h"
 
 namespace cnf {
 
@@ -410,55 +410,6 @@ struct alignas(16) SplitBwdLds {
     float wq[8];                          // quadrature weights of the current attempt
 };
 
-__device__ __forceinline__ float row16_allsum_s(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
-    return v;
-}
-
-struct BigAccS {
-    f32x4 gw[2][4];   // [layer][Tin]: lane (q, j') reg r = dW[16*wave+4q+r][16Tin+j']
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int l = 0; l < 2; ++l)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) gw[l][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-};
-
-// ---- cross-row reductions for the small-parameter gradients -----------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-
-// Sums of 8 values (a[0..3], b[0..3]) over the 16 rows of a tile (the 16 lanes of a DPP row), "transposed": every
-// exchange step halves the number of values a lane carries instead of reducing each value separately.  On return lane
-// j holds the two totals of index r* = j & 3:  ta = sum_rows a[r*],  tb = sum_rows b[r*]  (11 DPP adds + 12 selects
-// against 64 DPP adds for eight separate butterflies).  b0 = j & 1, b1 = j & 2.
-__device__ __forceinline__ void reduce8(const float (&a)[4], const float (&b)[4], bool b0, bool b1, float& ta, float& tb) {
-    const float a0 = (b0 ? a[1] : a[0]) + dpp_mov<0xB1>(b0 ? a[0] : a[1]);   // quad_perm [1,0,3,2]: rows j ^ 1
-    const float a1 = (b0 ? a[3] : a[2]) + dpp_mov<0xB1>(b0 ? a[2] : a[3]);
-    const float c0 = (b0 ? b[1] : b[0]) + dpp_mov<0xB1>(b0 ? b[0] : b[1]);
-    const float c1 = (b0 ? b[3] : b[2]) + dpp_mov<0xB1>(b0 ? b[2] : b[3]);
-    float aa = (b1 ? a1 : a0) + dpp_mov<0x4E>(b1 ? a0 : a1);                 // quad_perm [2,3,0,1]: rows j ^ 2
-    float cc = (b1 ? c1 : c0) + dpp_mov<0x4E>(b1 ? c0 : c1);
-    aa += dpp_mov<0x124>(aa);                                                // row_ror:4, row_ror:8: the lanes with equal j & 3
-    cc += dpp_mov<0x124>(cc);
-    aa += dpp_mov<0x128>(aa);
-    cc += dpp_mov<0x128>(cc);
-    ta = aa;
-    tb = cc;
-}
-
-// fire-and-forget LDS accumulate (ds_add_f32): every address has ONE owner lane per evaluation and a wave's LDS
-// operations complete in order, so the sums are deterministic
-__device__ __forceinline__ void lds_add(float* p, float v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // timing experiments only (tools/build_variants.sh): drop parts of the d/dtheta work to see what they cost
 #ifdef CNF_EXP_NO_SMALL
 constexpr bool kExpSmall = false;
@@ -833,17 +784,6 @@ __device__ inline void commit_step_fsal(SplitBwdLds<D>& sb, const BigAccS& acc, 
     __syncthreads();
 }
 
-template <int D>
-__device__ inline void stage_wimgT(float* img, const float* __restrict__ p, int tid) {
-    const ParamLayout L = make_layout(D, kH);
-    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += kThreads) {
-        const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
-        const int row = 16 * (tt & 3) + 4 * (lane >> 4) + r;
-        const int col = 16 * (tt >> 2) + (lane & 15);
-        img[idx] = p[L.w(1 + l) + row * kH + col];
-    }
-}
-
 // single augmented evaluation (cnf_eval_aug, rows <= 4096)
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float t, const float* __restrict__ z,
@@ -1171,6 +1111,11 @@ __global__ __launch_bounds__(256) void reduce_slab_split_kernel(const float* __r
     if (wv == 0 && p < P) out[p] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, slab, nwg, P, out);
+    return hipGetLastError();
+}
+
 template <int D, bool HUTCH>
 static hipError_t split_fwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
@@ -1209,7 +1154,10 @@ hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
     if (D == 1 && !hutch) return split_bwd_t<1, false>(a, s);
     if (D == 2 && !hutch) return split_bwd_t<2, false>(a, s);
     if (D == 2 && hutch) return split_bwd_t<2, true>(a, s);
-    if (D == 16 && hutch) return split_bwd_t<16, true>(a, s);
+    if (D == 16 && hutch) {
+        const uintptr_t al = (uintptr_t)a.x | (uintptr_t)a.e | (uintptr_t)a.grad_z1 | (uintptr_t)a.grad_x | (uintptr_t)a.params;
+        return (al & 15) == 0 ? launch_split16_bwd(a, s) : split_bwd_t<16, true>(a, s);
+    }
     return hipErrorNotSupported;
 }
 

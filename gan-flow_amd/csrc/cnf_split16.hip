@@ -12,7 +12,7 @@
 //     layout; the four waves' partial results meet in LDS (one ds_write_b128 / four ds_read_b128 per stream);
 //   * Runge-Kutta bookkeeping, error norms, I/O: 5 components per lane instead of 17, 16-byte loads and stores.
 // Hidden layers, gates, controller and grid reduction are those of dopri5_split_kernel.
-#include "cnf_launch.h"
+#include "cnf_split.h"
 
 namespace cnf {
 namespace {
@@ -33,7 +33,8 @@ struct alignas(16) Xchg16 {
 
 __device__ __forceinline__ f32x4 sum4v(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) { return ((a + b) + c) + d; }
 
-__device__ __forceinline__ void gates16(const NetLds<kD>& n, Wave16Lds& ws, int lane, float t) {
+template <class NET, class WS>
+__device__ __forceinline__ void gates16(const NET& n, WS& ws, int lane, float t) {
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
         const float g = sigmoid_f(fmaf(n.vec[l][2][lane], t, n.vec[l][3][lane]));
@@ -319,7 +320,595 @@ __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
     write_stats_global(a.stats, status, nfe, nacc, nrej, nfe, (float)dt, a.rows, tid);
 }
 
+
+// =====================================================================================================================
+// adjoint (mathematics of aug_eval_split, cnf_split.hip; state layout as above)
+// =====================================================================================================================
+struct alignas(16) Net16Lds {   // NetLds<16> without the first / last layer weights (they live in registers here)
+    float wimg[2][16][64][4];
+    float vec[3][4][kH];
+    float vec4[4][16];
+};
+
+__device__ inline void stage_net16(Net16Lds& n, const float* __restrict__ p, int tid) {
+    const ParamLayout L = make_layout(kD, kH);
+    float* img = &n.wimg[0][0][0][0];
+    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += kThreads) {
+        const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
+        const int row = 16 * (tt >> 2) + (lane & 15);
+        const int col = 16 * (tt & 3) + 4 * (lane >> 4) + r;
+        img[idx] = p[L.w(1 + l) + row * kH + col];
+    }
+    for (int idx = tid; idx < 3 * kH; idx += kThreads) {
+        const int l = idx / kH, i = idx % kH;
+        n.vec[l][0][i] = p[L.b(l) + i];
+        n.vec[l][1][i] = p[L.hb(l) + i];
+        n.vec[l][2][i] = p[L.wg(l) + i];
+        n.vec[l][3][i] = p[L.bg(l) + i];
+    }
+    if (tid < 16) {
+        n.vec4[0][tid] = p[L.b(3) + tid];
+        n.vec4[1][tid] = p[L.hb(3) + tid];
+        n.vec4[2][tid] = p[L.wg(3) + tid];
+        n.vec4[3][tid] = p[L.bg(3) + tid];
+    }
+}
+
+constexpr int kCA = 9;                       // components a lane integrates: 4 of z, logp, 4 of a_z
+constexpr int kCE = 5;                       // of which error-controlled: z and logp
+constexpr int kSmV = 3 * 4 * kH;             // vector parameters of the three hidden-output layers
+constexpr int kSm16 = kSmV + 4 * kD;         // + those of the last layer: [kind][dimension]
+
+struct alignas(16) Bwd16Lds {
+    float wimgT[2][16][64][4];          // transposed images of the two 64 x 64 matrices
+    float trB[2][2][kH * kRows];        // transposed layer inputs, all 64 features: [buffer][stream][feature * 16 + pos(row)]
+    float trA[kNW][2][16 * kRows];      // per wave: transposed, weighted cotangents of its own 16 features
+    float tX[kNW][2][16 * kRows];       // per wave: its tile of the last hidden layer's output, transposed (dW4's B operand)
+    float tU[2][16 * kRows];            // weighted cotangents of the 16 outputs, transposed (dW4's A operand)
+    float tZ[2][16 * kRows];            // [0] z, [1] e, transposed (dW1's B operands)
+    float small[kSm16];                 // d/dtheta of the vector parameters, weighted sum of the attempt
+    float wq[8];
+    // one copy for the four waves (they hold identical values; readers and the next evaluation's writers are
+    // separated by workgroup barriers), as are tU and tZ
+    float gate[3][2][kH];
+    float gate4[2][16];
+    float kst[7][kCA][64];
+};
+
+// One augmented evaluation.  Cotangents: -a_z on f, a_logp on the divergence estimate.  Outputs f4, div, vz4 =
+// (df/dz)^T(-a_z) + d(a_logp div)/dz (this lane's 4 components); with_theta: adds w * d/dtheta into acc (the two
+// 64 x 64 matrices), gw1 (W1 rows 16 wave + 4q + r, column j), gw4 (W4 rows 4q + r, column 16 wave + j), sb.small.
+__device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg16& xc, const f32x4& w1img, const f32x4& w4img,
+                                           const f32x4& w1Timg, const f32x4& w4Timg, int lane, int wave, float t,
+                                           const f32x4& z4, const f32x4& e4, const f32x4& az4, float al, float w,
+                                           bool with_theta, f32x4& f4, float& div, f32x4& vz4, BigAccS& acc, f32x4& gw1,
+                                           f32x4& gw4) {
+    const int q = lane >> 4, j = lane & 15, qq = j & 3;
+    const int fo = 16 * wave + 4 * q;
+    const int pos = (j & 3) * 4 + (j >> 2);
+    gates16(n, sb, lane, t);
+    const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0;
+    const int kind = j >> 2;
+    const float km0 = kind == 0 ? 1.f : 0.f, km1t = kind == 1 ? t : 0.f, km23 = kind == 2 ? t : (kind == 3 ? 1.f : 0.f);
+
+    // ------------------------------------------------------------------ forward with saves (own tile)
+    f32x4 xs[3], ub[3], U[3], act[2];
+    {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a = mfma16(w1img[r], z4[r], a);
+            au = mfma16(w1img[r], e4[r], au);
+        }
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&sb.gate[0][0][fo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&sb.gate[0][1][fo]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[0][0][fo]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
+            xs[0][r] = x;
+            ub[0][r] = a[r] + b[r];
+            U[0][r] = au[r];
+            act[0][r] = x;
+            act[1][r] = (1.0f - x * x) * g[r] * au[r];
+        }
+    }
+    if (with_theta) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sb.tZ[0][(4 * q + r) * kRows + pos] = z4[r];
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
+        __syncthreads();
+        f32x4 a4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&n.wimg[l][wave * 4 + Ti][lane][0]);
+            f32x4 in[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a4[s] = mfma16(a[r], in[s][r], a4[s]);
+        }
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&sb.gate[l + 1][0][fo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&sb.gate[l + 1][1][fo]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[l + 1][0][fo]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = tanh_f(fmaf(g[r], a4[0][r], c[r]));
+            xs[l + 1][r] = x;
+            ub[l + 1][r] = a4[0][r] + b[r];
+            U[l + 1][r] = a4[1][r];
+            act[0][r] = x;
+            act[1][r] = (1.0f - x * x) * g[r] * a4[1][r];
+        }
+    }
+    {
+        f32x4 pf = {0.f, 0.f, 0.f, 0.f}, pd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf = mfma16(w4img[r], act[0][r], pf);
+            pd = mfma16(w4img[r], act[1][r], pd);
+        }
+        *reinterpret_cast<f32x4*>(&xc.part[wave][0][lane][0]) = pf;
+        *reinterpret_cast<f32x4*>(&xc.part[wave][1][lane][0]) = pd;
+    }
+    __syncthreads();
+    const f32x4 u4 = sum4v(*reinterpret_cast<const f32x4*>(&xc.part[0][0][lane][0]), *reinterpret_cast<const f32x4*>(&xc.part[1][0][lane][0]),
+                           *reinterpret_cast<const f32x4*>(&xc.part[2][0][lane][0]), *reinterpret_cast<const f32x4*>(&xc.part[3][0][lane][0]));
+    const f32x4 U4 = sum4v(*reinterpret_cast<const f32x4*>(&xc.part[0][1][lane][0]), *reinterpret_cast<const f32x4*>(&xc.part[1][1][lane][0]),
+                           *reinterpret_cast<const f32x4*>(&xc.part[2][1][lane][0]), *reinterpret_cast<const f32x4*>(&xc.part[3][1][lane][0]));
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(&sb.gate4[0][4 * q]);
+    const f32x4 c4 = *reinterpret_cast<const f32x4*>(&sb.gate4[1][4 * q]);
+    {
+        float dpart = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f4[r] = fmaf(g4[r], u4[r], c4[r]);
+            dpart = fmaf(g4[r] * U4[r], e4[r], dpart);
+        }
+        div = xq_sum(dpart);
+    }
+
+    // ------------------------------------------------------------------ reverse sweep
+    f32x4 cot[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    {
+        f32x4 lf, ubar, Ubar;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            lf[r] = -az4[r];
+            ubar[r] = g4[r] * lf[r];
+            Ubar[r] = g4[r] * al * e4[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cot[0] = mfma16(w4Timg[r], ubar[r], cot[0]);
+            cot[1] = mfma16(w4Timg[r], Ubar[r], cot[1]);
+        }
+        if (with_theta) {
+            // dW4[m][feature] = sum_rows (ubar_m x + Ubar_m X): K = the 16 rows, both operands transposed through LDS
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sb.tU[0][(4 * q + r) * kRows + pos] = w * ubar[r];
+                sb.tU[1][(4 * q + r) * kRows + pos] = w * Ubar[r];
+                sb.tX[wave][0][(4 * q + r) * kRows + pos] = act[0][r];
+                sb.tX[wave][1][(4 * q + r) * kRows + pos] = act[1][r];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.tU[s][j * kRows + 4 * q]);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sb.tX[wave][s][j * kRows + 4 * q]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) gw4 = mfma16(a4[ks], b4[ks], gw4);
+            }
+            // bias, hyper-bias, gate weight, gate bias of the last layer: lane j < 4 of wave 0 owns kind j
+            const f32x4 bp = *reinterpret_cast<const f32x4*>(&n.vec4[0][4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s4 = row16_allsum_s(lf[r]);
+                const float gb = row16_allsum_s(lf[r] * (u4[r] + bp[r]) + al * e4[r] * U4[r]);
+                const float gg = g4[r] * (1.0f - g4[r]);
+                const float val = j < 2 ? s4 : gb;
+                const float fac = j == 0 ? g4[r] : (j == 1 ? t : (j == 2 ? t * gg : gg));
+                if (wave == 0 && j < 4) lds_add(&sb.small[kSmV + j * kD + 4 * q + r], w * fac * val);
+            }
+        }
+    }
+
+    auto issue_dw = [&](int lc) {
+        const int buf = 1 - lc;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.trA[wave][s][j * kRows + 4 * q]);
+            f32x4 b4[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) b4[T] = *reinterpret_cast<const f32x4*>(&sb.trB[buf][s][(16 * T + j) * kRows + 4 * q]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int Ti = 0; Ti < 4; ++Ti) acc.gw[lc][Ti] = mfma16(a4[ks], b4[Ti][ks], acc.gw[lc][Ti]);
+        }
+    };
+
+#pragma unroll
+    for (int l = 1; l >= -1; --l) {
+        const int L = l + 1;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&sb.gate[L][0][fo]);
+        float s1[4], s2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = xs[L][r];
+            const float dx = 1.0f - x * x;
+            const float Uk = U[L][r];
+            const float Xb = cot[1][r];
+            float pre = dx * cot[0][r];
+            pre = fmaf(Xb * (g[r] * Uk), -2.0f * x * dx, pre);
+            const float Pb = dx * Xb;
+            cot[1][r] = g[r] * Pb;
+            s1[r] = pre;
+            s2[r] = fmaf(pre, ub[L][r], Pb * Uk);
+            cot[0][r] = g[r] * pre;
+        }
+        if (with_theta) {
+            if (l < 1) issue_dw(l + 1);   // the previous layer's outer products, next to this vector work
+            float st, gt;
+            reduce8(s1, s2, b0, b1, st, gt);
+            const float gs = b1 ? (b0 ? g[3] : g[2]) : (b0 ? g[1] : g[0]);
+            const float gg = gs * (1.0f - gs);
+            const float fac = fmaf(gg, km23, fmaf(km0, gs, km1t));
+            lds_add(&sb.small[L * 4 * kH + kind * kH + fo + qq], w * fac * (kind < 2 ? st : gt));
+        }
+        if (l >= 0) {
+            const int lc = l < 0 ? 0 : l;
+            const int buf = 1 - lc;   // layer 3 publishes through buffer 0, layer 2 through buffer 1
+#pragma unroll
+            for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
+            if (with_theta) {
+                const f32x4 gi = *reinterpret_cast<const f32x4*>(&sb.gate[L - 1][0][fo]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xi = xs[L - 1][r];
+                    sb.trA[wave][0][(4 * q + r) * kRows + pos] = w * cot[0][r];
+                    sb.trA[wave][1][(4 * q + r) * kRows + pos] = w * cot[1][r];
+                    sb.trB[buf][0][(fo + r) * kRows + pos] = xi;
+                    sb.trB[buf][1][(fo + r) * kRows + pos] = (1.0f - xi * xi) * gi[r] * U[L - 1][r];
+                }
+            }
+            __syncthreads();
+            f32x4 o4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int To = 0; To < 4; ++To) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&sb.wimgT[lc][wave * 4 + To][lane][0]);
+                f32x4 in[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[buf][s][To][lane][0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) o4[s] = mfma16(a[r], in[s][r], o4[s]);
+            }
+            cot[0] = o4[0];
+            cot[1] = o4[1];
+        } else {
+            // (df/dz)^T: this wave's 16 features of the first layer's cotangent -> partial sums of all 16 components
+            f32x4 pz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pz = mfma16(w1Timg[r], cot[0][r], pz);
+            *reinterpret_cast<f32x4*>(&xc.part[wave][0][lane][0]) = pz;
+            if (with_theta) {
+                // dW1[feature][m] = sum_rows (cot z_m + tangent cotangent e_m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sb.trA[wave][0][(4 * q + r) * kRows + pos] = w * cot[0][r];
+                    sb.trA[wave][1][(4 * q + r) * kRows + pos] = w * cot[1][r];
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.trA[wave][s][j * kRows + 4 * q]);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sb.tZ[s][j * kRows + 4 * q]);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) gw1 = mfma16(a4[ks], b4[ks], gw1);
+                }
+            }
+            __syncthreads();
+            vz4 = sum4v(*reinterpret_cast<const f32x4*>(&xc.part[0][0][lane][0]), *reinterpret_cast<const f32x4*>(&xc.part[1][0][lane][0]),
+                        *reinterpret_cast<const f32x4*>(&xc.part[2][0][lane][0]), *reinterpret_cast<const f32x4*>(&xc.part[3][0][lane][0]));
+        }
+    }
+}
+
+// accepted step: the workgroup's sums go into its slab (stored, not added, by the first one: no zeroing pass needed)
+__device__ inline void commit16(Bwd16Lds& sb, const BigAccS& acc, const f32x4& gw1, const f32x4& gw4, float* __restrict__ slab_wg,
+                                int tid, bool first) {
+    const ParamLayout L = make_layout(kD, kH);
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    __syncthreads();
+    for (int i = tid; i < kSm16; i += kThreads) {
+        const int canon = i < kSmV ? L.b(i / (4 * kH)) + i % (4 * kH) : L.b(3) + (i - kSmV);
+        float* dst = &slab_wg[canon];
+        *dst = (first ? 0.f : *dst) + sb.small[i];
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* dst = &slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j];
+                *dst = (first ? 0.f : *dst) + acc.gw[l][Ti][r];
+            }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float* d1 = &slab_wg[L.w(0) + (16 * w + 4 * q + r) * kD + j];
+        *d1 = (first ? 0.f : *d1) + gw1[r];
+        float* d4 = &slab_wg[L.w(3) + (4 * q + r) * kH + 16 * w + j];
+        *d4 = (first ? 0.f : *d4) + gw4[r];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs a) {
+    __shared__ Net16Lds net;
+    __shared__ Bwd16Lds sb;
+    __shared__ Xchg16 xc;
+    __shared__ RedLds red;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int pos = (j & 3) * 4 + (j >> 2);
+    if (tid == 0) red.status = 0;
+    stage_net16(net, a.params, tid);
+    stage_wimgT<kD>(&sb.wimgT[0][0][0][0], a.params, tid);
+    for (int i = tid; i < 7 * kCA * 64; i += kThreads) (&sb.kst[0][0][0])[i] = 0.f;
+    for (int i = tid; i < kSm16; i += kThreads) sb.small[i] = 0.f;
+    const ParamLayout L = make_layout(kD, kH);
+    const f32x4 w1img = *reinterpret_cast<const f32x4*>(a.params + L.w(0) + (16 * w + j) * kD + 4 * q);
+    const f32x4 w4img = *reinterpret_cast<const f32x4*>(a.params + L.w(3) + j * kH + 16 * w + 4 * q);
+    f32x4 w1Timg, w4Timg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        w1Timg[r] = a.params[L.w(0) + (16 * w + 4 * q + r) * kD + j];
+        w4Timg[r] = a.params[L.w(3) + (4 * q + r) * kH + 16 * w + j];
+    }
+    const long row = (long)blockIdx.x * kRows + j;
+    const bool valid = row < a.rows;
+    const bool cz = valid && w == 0;
+    const bool cl = cz && q == 0;
+    const long rr = valid ? row : a.rows - 1;
+    float* slab = a.slab + (size_t)blockIdx.x * L.total;
+
+    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    const double nl = (double)a.rows, nz = nl * kD;
+
+    float y0[kCA], y1[kCA], yi[kCA];
+    const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.e + rr * kD + 4 * q);
+    {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(a.x + rr * kD + 4 * q);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.grad_z1 + rr * kD + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            y0[r] = x4[r];
+            y0[5 + r] = valid ? g4[r] : 0.f;
+            sb.tZ[1][(4 * q + r) * kRows + pos] = e4[r];
+        }
+    }
+    y0[4] = a.logp0[rr];
+    const float al = valid ? a.grad_logp1[rr] : 0.f;
+#pragma unroll
+    for (int c = 0; c < kCA; ++c) yi[c] = y0[c];
+    __syncthreads();
+
+    const float sgn = a.t0 >= a.t1 ? 1.f : -1.f;
+    const double tau_end = (double)(sgn * a.t0);
+    double tau = (double)(sgn * a.t1);
+    double dt = 0.0;
+    float dtf = 0.f, t0f = (float)tau, ti = t0f;
+    const float rtol = a.rtol, atol = a.atol;
+
+    enum { PH_F0 = 0, PH_F1 = 1, PH_STAGE = 2 };
+    int phase = PH_F0, stage = 0;
+    int nacc = 0, nrej = 0, status = 0, nrun = 0;
+    float h0 = 0.f, d1z = 0.f, d1l = 0.f;
+    float sc[kCE];
+    BigAccS acc;
+    acc.zero();
+    f32x4 gw1 = {0.f, 0.f, 0.f, 0.f}, gw4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (;;) {
+        f32x4 z4, az4, f4, vz4;
+        float div, k[kCA];
+        bool restart = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            z4[r] = yi[r];
+            az4[r] = yi[5 + r];
+        }
+        const float wst = phase == PH_STAGE ? sb.wq[stage] : 0.f;
+        const bool with_theta = wst != 0.f;
+        aug_eval16(net, sb, xc, w1img, w4img, w1Timg, w4Timg, lane, w, sgn * ti, z4, e4, az4, al, sgn * wst, with_theta, f4, div,
+                   vz4, acc, gw1, gw4);
+        ++nrun;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            k[r] = sgn * f4[r];
+            k[5 + r] = sgn * vz4[r];
+        }
+        k[4] = -sgn * div;
+
+        if (phase == PH_F0) {
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < kCA; ++c) sb.kst[0][c][lane] = k[c];
+#pragma unroll
+            for (int c = 0; c < kCE; ++c) {
+                sc[c] = atol + fabsf(y0[c]) * rtol;
+                const float u = y0[c] / sc[c], v = k[c] / sc[c];
+                if (c < 4 ? cz : cl) {
+                    S[c < 4 ? 0 : 1] += (double)u * u;
+                    S[c < 4 ? 2 : 3] += (double)v * v;
+                }
+            }
+            if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
+            d1z = (float)sqrt(S[2] / nz);
+            d1l = (float)sqrt(S[3] / nl);
+            if (pymax(d0z, d0l) < 1e-5f || pymax(d1z, d1l) < 1e-5f) {
+                h0 = 1e-6f;
+            } else {
+                h0 = 0.01f * pymax(d0z / d1z, d0l / d1l);
+            }
+#pragma unroll
+            for (int c = 0; c < kCA; ++c) yi[c] = y0[c] + h0 * k[c];
+            ti = t0f + h0;
+            phase = PH_F1;
+            continue;
+        }
+        if (phase == PH_F1) {
+            double S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < kCE; ++c) {
+                const float u = (k[c] - sb.kst[0][c][lane]) / sc[c];
+                if (c < 4 ? cz : cl) S[c < 4 ? 0 : 1] += (double)u * u;
+            }
+            if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
+            float h1;
+            if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
+                h1 = fmaxf(1e-6f, h0 * 1e-3f);
+            } else {
+                h1 = powf(0.01f / pymax(pymax(pymax(d1z, d1l), d2z), d2l), 0.2f);
+            }
+            dt = (double)fminf(100.f * h0, h1);
+            restart = true;
+        } else {
+#pragma unroll
+            for (int c = 0; c < kCA; ++c) sb.kst[stage][c][lane] = k[c];
+            if (stage < 6) {
+                ++stage;
+            } else {
+                double S[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < kCA; ++c) y1[c] = yi[c];
+#pragma unroll
+                for (int c = 0; c < kCE; ++c) {
+                    float err = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * sb.kst[s][c][lane];
+                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c]));
+                    const float u = err / tol;
+                    if (c < 4 ? cz : cl) {
+                        S[c < 4 ? 0 : 1] += (double)u * u;
+                        if (!isfinite(y0[c])) S[2] += 1.0;
+                    }
+                }
+                if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
+                const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
+                const bool accept = (rz <= 1.f) && (rl <= 1.f);
+                if (accept) {
+                    ++nacc;
+                    commit16(sb, acc, gw1, gw4, slab, tid, nacc == 1);
+                    if (!(tau_end > tau + dt)) break;
+#pragma unroll
+                    for (int c = 0; c < kCA; ++c) y0[c] = y1[c];
+                    tau = tau + dt;
+                } else {
+                    ++nrej;
+                }
+                dt = next_step_size(dt, pymax(rz, rl));
+                restart = true;
+            }
+        }
+        if (restart) {
+            if (!(tau + dt > tau)) { status = CNF_ERR_DT_UNDERFLOW; break; }
+            if (nacc + nrej >= a.max_steps) { status = CNF_ERR_MAX_STEPS; break; }
+            dtf = (float)dt;
+            t0f = (float)tau;
+            stage = 0;
+            phase = PH_STAGE;
+            acc.zero();
+            gw1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            gw4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();   // every wave is past its last read of small / wq of the previous attempt
+            for (int i = tid; i < kSm16; i += kThreads) sb.small[i] = 0.f;
+            if (tid < 7) {
+                const int s = tid;
+                float v;
+                if (tau_end > tau + dt) {
+                    v = s < 6 ? dtf * kBeta[5][s] : 0.f;
+                } else {
+                    const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+                    const float x = (te - ta) / (tb - ta);
+                    const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+                    const float b = s < 6 ? kBeta[5][s] : 0.f;
+                    const float cm = kCMid[s];
+                    v = dtf * (x4 * (-8.f * b + 16.f * cm) + x3 * (14.f * b - 32.f * cm) + x2 * (-5.f * b + 16.f * cm));
+                    if (s == 0) v += dtf * (-2.f * x4 + 5.f * x3 - 4.f * x2 + x);
+                    if (s == 6) v += dtf * (2.f * x4 - 3.f * x3 + x2);
+                }
+                sb.wq[s] = v;
+            }
+            __syncthreads();
+        }
+        if (stage == 0) {
+            ti = t0f;
+#pragma unroll
+            for (int c = 0; c < kCA; ++c) yi[c] = y0[c];
+        } else {
+            float alpha_, bc_[6];
+            stage_coeffs(stage, alpha_, bc_);
+            ti = t0f + alpha_ * dtf;
+#pragma unroll
+            for (int c = 0; c < kCA; ++c) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) s_ += (dtf * bc_[s]) * sb.kst[s][c][lane];   // zero weights past the current stage
+                yi[c] = y0[c] + s_;
+            }
+        }
+    }
+
+    if (status == 0) {
+        const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+        const float x = (te - ta) / (tb - ta);
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 5 + r;
+            float mid = 0.f;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * sb.kst[s][c][lane];
+            mid = y0[c] + mid;
+            const float f0 = sb.kst[0][c][lane], f1 = sb.kst[6][c][lane], u = y0[c], v = y1[c];
+            const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
+            const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
+            const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
+            const float cd = dtf * f0;
+            o[r] = ca * x4 + cb * x3 + cc * x2 + cd * x + u;
+        }
+        if (cz) *reinterpret_cast<f32x4*>(a.grad_x + row * kD + 4 * q) = o;
+        if (cl) a.grad_logp0[row] = al;
+    }
+    grid_cleanup(gs, red, tid);
+    write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
+}
+
 }  // namespace
+
+hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s) {
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    dbg_timing_begin(s);
+    hipLaunchKernelGGL(dopri5_bwd_split16_kernel, dim3(grid), dim3(kThreads), 0, s, a);
+    dbg_timing_end(s);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    return launch_reduce_slab(a.slab, grid, make_layout(kD, kH).total, a.grad_params, s);
+}
 
 hipError_t launch_split16_fwd(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
