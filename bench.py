@@ -211,14 +211,15 @@ def main():
 
 def measure_roofline(ctx):
     """Dominant kernel = the adjoint solve.  achieved = algorithmic FLOP per launch (rows x NFE x 3 x F_eval, NFE as the
-    reference counts it) / mean launch duration, HIP events on the launch stream (torch's current stream)."""
+    reference counts it; the state work a CNF_FLAG_SPREAD launch does twice is counted once) / mean launch duration, HIP
+    events on the launch stream (torch's current stream)."""
     from gan_flow_amd import _native
     args, model, batches = ctx["args"], ctx["model"], ctx["batches"]
     blk = model.chain[0]
     fn = blk.odefunc.odefunc
     net = fn.net_desc()
     params = fn.diffeq.flat_parameters().detach()
-    opts = _native.make_opts("dopri5", blk.rtol, blk.atol)
+    opts = _native.make_opts("dopri5", blk.rtol, blk.atol, flags=_native.FLAG_SPREAD)   # as the timed training step launches it
     T = float(blk.sqrt_end_time.detach() ** 2)
     x = batches[-1]
     z1, l1, _ = _native.solve_fwd(net, params, x, None, 0.0, T, opts)
@@ -241,7 +242,7 @@ def measure_roofline(ctx):
     flops = args.batch * st.nfe * 3 * F_EVAL_D2
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None   # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/): not measurable in-process
-    tpath = os.path.join(ROOT, "profiles", "r01e_bwd_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01f_bwd_traffic.json")
     if os.path.exists(tpath) and args.batch == 2048:
         with open(tpath) as fh:
             traffic = json.load(fh)["hbm_bytes_per_launch"]
@@ -316,7 +317,7 @@ def measure_pair(ctx):
             if late:
                 model = embed_trained_multimodal(model)
             model = model.to(dev).train()
-            trials.append(gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True,
+            trials.append(gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True, spread=False,
                                                    warmup_batches=xs[:1 if late else max(1, args.warmup)]))
             feeds.append(xs[args.warmup:])
         both = gu_ffjord.ConcurrentTrials(trials)

@@ -111,8 +111,15 @@ int check_adjoint_rows(const char* who, const CnfNetDesc* n, long rows) {
                     cnf::kRows * cnf::kMaxWG, rows);
     return 0;
 }
+// CNF_FLAG_SPREAD applies to the one-tile-per-workgroup adjoint at dim <= 2 when twice the tiles still fit the device
+bool can_spread(const CnfNetDesc* n, long rows, int cus) {
+    const long tiles = (rows + cnf::kRows - 1) / cnf::kRows;
+    return !is_wide(n) && n->dim <= 2 && use_split(n, rows) && 2 * tiles <= cnf::kMaxWG && 2 * tiles <= cus;
+}
 long n_slabs(const CnfNetDesc* n, long rows) {
-    return use_split(n, rows) ? (rows + cnf::kRows - 1) / cnf::kRows : n_wg(rows);
+    if (!use_split(n, rows)) return n_wg(rows);
+    const long tiles = (rows + cnf::kRows - 1) / cnf::kRows;
+    return can_spread(n, rows, cnf::kMaxWG) ? 2 * tiles : tiles;   // room for a spread launch whether or not it is asked for
 }
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -318,6 +325,7 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     a.grad_x = grad_x;
     a.grad_logp0 = grad_logp0;
     a.grad_params = grad_params;
+    a.spread = (opts->flags & CNF_FLAG_SPREAD) && can_spread(net, rows, device_cus()) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (is_wide(net)) {
         if (((uintptr_t)params & 15) != 0) return fail("cnf_solve_bwd: params must be 16-byte aligned for hidden width 256");

@@ -27,6 +27,7 @@ struct SolveArgs {
     float* grad_logp0;
     float* grad_params;
     float* slab;          // per-workgroup parameter-gradient partials [nwg][P]
+    int spread;           // adjoint, cnf_split.hip: two workgroups per tile, each keeping half of the d/dtheta sums
 };
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,

@@ -427,10 +427,13 @@ template <int D, bool HUTCH, class WS>
 __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D>& sb, WS& ws, SplitXchg<D>& xc, int lane,
                                                int wave, float t, const float (&z)[D], const float (&e)[D],
                                                const float (&az)[D], float al, float w, bool with_theta, float (&f)[D],
-                                               float& div, float (&vz)[D], BigAccS& acc, int small_base) {
+                                               float& div, float (&vz)[D], BigAccS& acc, int small_base, int part = 0) {
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     using SI = SmallIdxS<D>;
+    // part (uniform over the workgroup): which d/dtheta sums this workgroup keeps.  0 = all; 1 = the upper half
+    // (W3, layer-3 vectors, W4, layer-4 vectors); 2 = the lower half (W1, layer-1/2 vectors, W2).  See kSpreadNote.
+    const bool th_hi = with_theta && part != 2, th_lo = with_theta && part != 1;
     float* const small = &sb.small[0][0] + small_base;   // an LDS address the compiler can see (no flat atomics)
     const int q = lane >> 4, j = lane & 15, qq = j & 3;
     const int fo = 16 * wave + 4 * q;
@@ -563,7 +566,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
             cot[0][r] = xb;
             if (HUTCH) cot[1][r] = Xh;
         }
-        if (with_theta && kExpSmall) {
+        if (th_hi && kExpSmall) {
             // d/dW4[m][feature] = sum_rows (ubar_m x + Ubar_m X_m): two output rows m per reduce8
 #pragma unroll
             for (int m = 0; m < D; m += 2) {
@@ -577,7 +580,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 if (kind < 2 && m + kind < D) lds_add(&small[SI::l4 + (m + kind) * kH + fo + qq], w * (kind == 0 ? ta : tb));
             }
         }
-        if (with_theta) {
+        if (th_hi) {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 const float s4 = row16_allsum_s(lf[m]);
@@ -641,10 +644,10 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
             s2[r] = fmaf(pre, ub[L][r], q2);
             cot[0][r] = g[r] * pre;
         }
-        if (with_theta) {
+        if (l == 0 ? th_hi : th_lo) {
             if (kExpDw && l < 1) issue_dw(l + 1);   // the previous layer's outer products, next to this vector work
         }
-        if (with_theta && kExpSmall) {
+        if ((L == 2 ? th_hi : th_lo) && kExpSmall) {
             // every lane ends up owning one (feature fo + r*, kind) entry of this layer's four vectors: no branch, no idle lane
             float st, gt;
             reduce8(s1, s2, b0, b1, st, gt);
@@ -658,7 +661,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
             const int buf = 1 - lc;   // layer 3 publishes through buffer 0, layer 2 through buffer 1
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
-            if (with_theta && kExpDw) {
+            if ((lc == 1 ? th_hi : th_lo) && kExpDw) {
                 const f32x4 gi = *reinterpret_cast<const f32x4*>(&ws.gate[L - 1][0][fo]);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -713,7 +716,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 pz = xq_sum(pz);
                 if (q == 0) sb.part2[wave][m][j] = pz;
             }
-            if (with_theta && kExpSmall) {
+            if (th_lo && kExpSmall) {
                 // d/dW1[feature][m] = sum_rows (cot z_m + tangent cotangent_m): two input columns m per reduce8
 #pragma unroll
                 for (int m = 0; m < D; m += 2) {
@@ -738,17 +741,19 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
 
 template <int D>
 __device__ inline void commit_step_split(SplitBwdLds<D>& sb, const BigAccS& acc, float* __restrict__ slab_wg, int tid,
-                                         bool first = false) {
+                                         bool first = false, int part = 0) {
     const ParamLayout L = make_layout(D, kH);
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int i_lo = part == 1 ? SmallIdxS<D>::v3 : 0, i_hi = part == 2 ? SmallIdxS<D>::v3 : SmallIdxS<D>::count;
     __syncthreads();
     // first: the slab has not been written yet (and need not have been zeroed): store instead of accumulate
-    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads) {
+    for (int i = i_lo + tid; i < i_hi; i += kThreads) {
         float* dst = &slab_wg[SmallIdxS<D>::canonical(i)];
         *dst = (first ? 0.f : *dst) + sb.small[0][i];
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l)
+        if (part == 0 || part == 2 - l)
 #pragma unroll
         for (int Ti = 0; Ti < 4; ++Ti)
 #pragma unroll
@@ -763,16 +768,18 @@ __device__ inline void commit_step_split(SplitBwdLds<D>& sb, const BigAccS& acc,
 template <int D>
 __device__ inline void commit_step_fsal(SplitBwdLds<D>& sb, const BigAccS& acc, const BigAccS& gfirst, const BigAccS& glast,
                                         int i_first, int i_last, float w_first, float w_last,
-                                        float* __restrict__ slab_wg, int tid, bool first) {
+                                        float* __restrict__ slab_wg, int tid, bool first, int part) {
     const ParamLayout L = make_layout(D, kH);
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int i_lo = part == 1 ? SmallIdxS<D>::v3 : 0, i_hi = part == 2 ? SmallIdxS<D>::v3 : SmallIdxS<D>::count;
     __syncthreads();
-    for (int i = tid; i < SmallIdxS<D>::count; i += kThreads) {
+    for (int i = i_lo + tid; i < i_hi; i += kThreads) {
         float* dst = &slab_wg[SmallIdxS<D>::canonical(i)];
         *dst = (first ? 0.f : *dst) + fmaf(w_last, sb.small[i_last][i], fmaf(w_first, sb.small[i_first][i], sb.small[0][i]));
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l)
+        if (part == 0 || part == 2 - l)
 #pragma unroll
         for (int Ti = 0; Ti < 4; ++Ti)
 #pragma unroll
@@ -841,9 +848,15 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid);
     for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += kThreads) (&sb.small[0][0])[i] = 0.f;
     __syncthreads();
-    const long row = (long)blockIdx.x * kRows + j;
+    // kSpreadNote -- a.spread: TWO workgroups per 16-row tile (grid = 2 x tiles, for batches that would leave half the
+    // compute units idle).  Both integrate the tile's state identically -- same arithmetic, same totals from the grid
+    // reductions, same decisions -- but each keeps only half of the d/dtheta sums (part 1 / part 2, aug_eval_split), which
+    // is a third of an augmented evaluation's time.  Only the even workgroup counts its rows and writes grad_x.
+    const int tile = a.spread ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int part = a.spread ? 1 + (int)(blockIdx.x & 1) : 0;
+    const long row = (long)tile * kRows + j;
     const bool valid = row < a.rows;
-    const bool counted = valid && lane < 16 && w == 0;
+    const bool counted = valid && lane < 16 && w == 0 && part != 2;
     const long rr = valid ? row : a.rows - 1;
     SplitWaveLds<C>& ws = wl[kShareWaveLds<D> ? 0 : w];
     float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;
@@ -902,7 +915,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             keep = acc;
             acc.zero();
         }
-        aug_eval_split<D, HUTCH>(net, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc, small);
+        aug_eval_split<D, HUTCH>(net, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc, small, part);
         if (FSAL && (to_first || to_last)) {
             if (to_first) gfirst = acc;
             else glast = acc;
@@ -989,8 +1002,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                 const bool accept = (rz <= 1.f) && (rl <= 1.f);
                 if (accept) {
                     ++nacc;
-                    if (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid, nacc == 1);
-                    else commit_step_split<D>(sb, acc, slab, tid, nacc == 1);
+                    if (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid, nacc == 1, part);
+                    else commit_step_split<D>(sb, acc, slab, tid, nacc == 1, part);
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
                     for (int c = 0; c < C; ++c) y0[c] = y1[c];
@@ -1089,22 +1102,26 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
 // Sum of the workgroups' slabs in a FIXED order (deterministic gradients).  64 parameters per block; the four waves
 // of a block take the slabs g = wave, wave + 4, ... (eight independent loads in flight per thread), LDS combines the
 // four partial sums as (w0 + w1) + (w2 + w3).
+// split_at > 0 (spread launches): tile g's sums for parameter p live in slab 2g (p >= split_at) or 2g + 1 (p < split_at);
+// the order of the additions over tiles is that of an ordinary launch, so the two modes give identical sums.
 __global__ __launch_bounds__(256) void reduce_slab_split_kernel(const float* __restrict__ slab, int nwg, int P,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, int split_at) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + lane;
     float acc = 0.f;
     if (p < P) {
+        const size_t stride = split_at > 0 ? 2 * (size_t)P : (size_t)P;
+        const float* src = slab + p + (split_at > 0 && p < split_at ? (size_t)P : 0);
         int g = wv;
         for (; g + 28 < nwg; g += 32) {
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = slab[(size_t)(g + 4 * k) * P + p];
+            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(g + 4 * k) * stride];
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc += v[k];
         }
-        for (; g < nwg; g += 4) acc += slab[(size_t)g * P + p];
+        for (; g < nwg; g += 4) acc += src[(size_t)g * stride];
     }
     part[wv][lane] = acc;
     __syncthreads();
@@ -1112,7 +1129,7 @@ __global__ __launch_bounds__(256) void reduce_slab_split_kernel(const float* __r
 }
 
 hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, slab, nwg, P, out);
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, slab, nwg, P, out, 0);
     return hipGetLastError();
 }
 
@@ -1141,12 +1158,14 @@ template <int D, bool HUTCH>
 static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
     dbg_timing_begin(s);
-    hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH>), dim3(a.spread ? 2 * grid : grid), dim3(kThreads), 0, s, a);
     dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
-    const int P = make_layout(D, kH).total;
-    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, a.slab, grid, P, a.grad_params);
+    const ParamLayout L = make_layout(D, kH);
+    const int P = L.total;
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, a.slab, grid, P, a.grad_params,
+                       a.spread ? L.w(2) : 0);
     return hipGetLastError();
 }
 
@@ -1169,7 +1188,7 @@ static hipError_t split_aug_t(const SolveArgs& a, float t, const float* z, const
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     const int P = make_layout(D, kH).total;
-    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, a.slab, grid, P, a.grad_params);
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, a.slab, grid, P, a.grad_params, 0);
     return hipGetLastError();
 }
 

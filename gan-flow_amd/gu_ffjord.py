@@ -140,7 +140,11 @@ class FusedTrainStep:
     device until .check()."""
 
     def __init__(self, model, example_batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, graph=True,
-                 warmup_batches=()):
+                 warmup_batches=(), spread=True):
+        # spread: flag the adjoint solves CNF_FLAG_SPREAD (include/cnf_hip.h): two workgroups per 16-row tile when the
+        # batch would leave half the compute units idle.  Same results; must be False for trials that share a GPU
+        # (ConcurrentTrials), whose solves have to be resident side by side.
+        self.spread = bool(spread)
         from . import _native
         from .lib.layers.cnf import _inner
         self._native, self.model = _native, model
@@ -197,6 +201,8 @@ class FusedTrainStep:
             net, t0, t1, opts, e = blk.solve_plan(z, reset_counter=False)
             if opts.solver == 0 and opts.tile_rows == 0:
                 opts.flags |= nat.FLAG_CLEAN
+            if self.spread:
+                opts.flags |= nat.FLAG_SPREAD
             z, lp, _ = nat.solve_fwd(net, self.flats[i], z, lp, t0, t1, opts, e, stats=self.stats[i, 0], workspace=self.workspace)
             tape.append((net, t0, t1, opts, e, z, lp))
         loss, gz, gl = nat.nll_loss(z, lp)
@@ -270,6 +276,9 @@ class ConcurrentTrials:
         self.trials = list(trials)
         if not self.trials or any(t.graph is None for t in self.trials):
             raise ValueError("ConcurrentTrials needs FusedTrainStep objects built with graph=True")
+        if any(t.spread for t in self.trials):
+            raise ValueError("ConcurrentTrials needs FusedTrainStep objects built with spread=False: a spread adjoint "
+                             "occupies every compute unit and cannot be resident next to another trial's solve")
         dev = self.trials[0].static_x.device
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         need = sum((t.static_x.shape[0] + 15) // 16 for t in self.trials)

@@ -315,3 +315,35 @@ def test_flag_clean_calls_match_zeroing_calls(dim, hidden, rows):
             assert torch.equal(a.cpu(), b.cpu())
         assert nat.Stats(sf).status == 0 and nat.Stats(sb).status == 0
     assert nat.Stats(sb).n_accepted < 3
+
+
+@pytest.mark.parametrize("dim,hutch,rows", [(2, False, 2048), (2, False, 100), (1, False, 1000), (2, True, 256), (2, False, 1),
+                                            (2, False, 2064)])
+def test_spread_adjoint_equals_plain_adjoint(dim, hutch, rows):
+    """CNF_FLAG_SPREAD (include/cnf_hip.h): two workgroups per 16-row tile, each keeping half of the d/dtheta sums.  The
+    arithmetic per tile and the order of the additions over tiles are those of the plain launch, so everything the call
+    returns is identical bit for bit (2064 rows = 129 tiles do not fit twice: the flag is ignored there)."""
+    nat = _native()
+    g = torch.Generator().manual_seed(31)
+    m = oracle_random_model(dim, seed=9, divergence_fn="approximate" if hutch else "brute_force", scale=2.0)
+    net = nat.net_desc(dim, 64, 3, hutch)
+    params = _flat(m).to(DEV)
+    x = torch.randn(rows, dim, generator=g).to(DEV)
+    e = torch.randn(rows, dim, generator=g).to(DEV) if hutch else None
+    plain = nat.make_opts("dopri5", 1e-5, 1e-5)
+    z1, l1, _ = nat.solve_fwd(net, params, x, None, 0.0, 0.5, plain, e)
+    gz1 = z1 / rows
+    gl1 = torch.full((rows, 1), 1.0 / rows, device=DEV)
+    outs = []
+    for flags in (0, nat.FLAG_SPREAD, nat.FLAG_SPREAD):
+        o = nat.make_opts("dopri5", 1e-5, 1e-5, flags=flags)
+        gx, gl0, gp, st = nat.solve_bwd(net, params, z1, l1, gz1, gl1, 0.0, 0.5, o, e)
+        torch.cuda.synchronize()
+        st = nat.Stats(st)
+        st.raise_for_status()
+        outs.append((gx.clone(), gl0.clone(), gp.clone(), (st.nfe, st.n_accepted, st.n_rejected, st.evals_run)))
+    for other in outs[1:]:
+        assert other[3] == outs[0][3]
+        assert torch.equal(other[0], outs[0][0]) and torch.equal(other[1], outs[0][1])
+        assert torch.equal(other[2], outs[0][2])
+    assert outs[0][2].abs().max().item() > 0

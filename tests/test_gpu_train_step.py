@@ -159,14 +159,14 @@ def test_concurrent_trials_match_sequential():
     datas = [make_gu(8, seed=11), make_gu(8, seed=12)]
     batches = [[d.get_sample(2048).to(DEV) for _ in range(10)] for d in datas]
 
-    def build(seed, bs):
+    def build(seed, bs, spread=False):
         torch.manual_seed(seed)
         model = gu_ffjord.build_model(2).to(DEV).train()
-        return model, gu_ffjord.FusedTrainStep(model, bs[0], lr=1e-3, weight_decay=1e-5, graph=True)
+        return model, gu_ffjord.FusedTrainStep(model, bs[0], lr=1e-3, weight_decay=1e-5, graph=True, spread=spread)
 
     alone = []
     for k in range(2):
-        _, step = build(20 + k, batches[k])
+        _, step = build(20 + k, batches[k], spread=True)   # alone: two workgroups per tile (CNF_FLAG_SPREAD) -- same trajectory
         alone.append([step(x).item() for x in batches[k]])
         step.check()
     pairs = [build(20 + k, batches[k]) for k in range(2)]
@@ -181,3 +181,5 @@ def test_concurrent_trials_match_sequential():
     assert together == alone
     with pytest.raises(ValueError):
         gu_ffjord.ConcurrentTrials([p[1] for p in pairs] * 2)        # 4 x 128 workgroups do not fit 256 compute units
+    with pytest.raises(ValueError):
+        gu_ffjord.ConcurrentTrials([pairs[0][1], step])              # a spread trial cannot share the GPU

@@ -21,7 +21,7 @@ for k in range(2):
     x = data.get_sample(2048).to(dev)
     torch.manual_seed(101 + k)
     model = bench.embed_trained_multimodal(gu_ffjord.build_model(2)).to(dev).train()
-    trials.append(gu_ffjord.FusedTrainStep(model, x, lr=1e-3, weight_decay=1e-5, graph=True, warmup_batches=[x]))
+    trials.append(gu_ffjord.FusedTrainStep(model, x, lr=1e-3, weight_decay=1e-5, graph=True, spread=False, warmup_batches=[x]))
     xs.append(x)
 both = gu_ffjord.ConcurrentTrials(trials)
 
@@ -50,7 +50,7 @@ trials = []
 for k in range(2):
     torch.manual_seed(101 + k)
     model = bench.embed_trained_multimodal(gu_ffjord.build_model(2)).to(dev).train()
-    trials.append(gu_ffjord.FusedTrainStep(model, xs[k], lr=1e-3, weight_decay=1e-5, graph=True, warmup_batches=[xs[k]]))
+    trials.append(gu_ffjord.FusedTrainStep(model, xs[k], lr=1e-3, weight_decay=1e-5, graph=True, spread=False, warmup_batches=[xs[k]]))
 both = gu_ffjord.ConcurrentTrials(trials)
 timed("new trials (graphs captured after the d=16 kernel ran)")
 both = gu_ffjord.ConcurrentTrials(trials)
@@ -68,6 +68,6 @@ trials = []
 for k in range(2):
     torch.manual_seed(101 + k)
     model = bench.embed_trained_multimodal(gu_ffjord.build_model(2)).to(dev).train()
-    trials.append(gu_ffjord.FusedTrainStep(model, xs[k], lr=1e-3, weight_decay=1e-5, graph=True, warmup_batches=[xs[k]]))
+    trials.append(gu_ffjord.FusedTrainStep(model, xs[k], lr=1e-3, weight_decay=1e-5, graph=True, spread=False, warmup_batches=[xs[k]]))
 both = gu_ffjord.ConcurrentTrials(trials)
 timed("new trials after that")

@@ -15,6 +15,7 @@ from gan_flow_amd.gu import make_gu  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+SPREAD = (sys.argv[2] if len(sys.argv) > 2 else "spread") == "spread"   # adjoint launched as the training step launches it
 reps = 5
 x = make_gu(8, seed=1).get_sample(B).to(dev)
 for name in ("early", "late"):
@@ -29,6 +30,8 @@ for name in ("early", "late"):
     opts = nat.make_opts("dopri5", 1e-5, 1e-5)
     z1, l1, sf = nat.solve_fwd(net, params, x, None, 0.0, T, opts)
     gz, gl = z1 / B, torch.full_like(l1, 1.0 / B)
+    if SPREAD:
+        opts = nat.make_opts("dopri5", 1e-5, 1e-5, flags=nat.FLAG_SPREAD)
     nat.solve_bwd(net, params, z1, l1, gz, gl, 0.0, T, opts)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
