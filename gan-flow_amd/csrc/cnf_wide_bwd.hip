@@ -62,10 +62,13 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
                                               const float* __restrict__ wt, int lane, int wave, float t,
                                               const float (&z)[D], const float (&e)[D], const float (&az)[D], float al,
                                               float w, bool with_theta, float (&f)[D], float& div, float (&vz)[D],
-                                              float* __restrict__ slot) {
+                                              float* __restrict__ slot, int part = 0) {
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     using SI = WideSmallIdx<D>;
+    // part: which d/dtheta sums this workgroup writes (CNF_FLAG_SPREAD, kSpreadNote in cnf_split.hip): 0 = all,
+    // 1 = W3, layer-3 vectors, layer 4; 2 = W1, layer-1/2 vectors, W2
+    const bool th_hi = with_theta && part != 2, th_lo = with_theta && part != 1;
     const int q = lane >> 4, j = lane & 15, qq = j & 3;
     const int g0 = (((j >> 2) * 16 + 4 * q) * 4) + (j & 3);   // gather offset of (feature tile-local j, row 4q + ks): + 4 ks
     float* slot_small = slot + kWideBig;
@@ -230,7 +233,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
                 }
                 cot[0][T][r] = xb;
                 if (HUTCH) cot[1][T][r] = Xh;
-                if (with_theta) {
+                if (th_hi) {
                     float mine = 0.f;
 #pragma unroll
                     for (int m = 0; m < D; ++m) {
@@ -241,7 +244,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
                 }
             }
         }
-        if (with_theta) {
+        if (th_hi) {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 const float s4 = row16_allsum_w(lf[m]);
@@ -290,7 +293,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
                 s2[r] = fmaf(pre, ub[L][T][r], q2);
                 cot[0][T][r] = g[r] * pre;
             }
-            if (with_theta) {
+            if (L == 2 ? th_hi : th_lo) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float st = row16_allsum_w(s1[r]);
@@ -311,7 +314,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
             for (int T = 0; T < kWTW; ++T)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[0][s][kWTW * wave + T][lane][0]) = cot[s][T];
-            if (lc == 0 && with_theta) {
+            if (lc == 0 && th_lo) {
 #pragma unroll
                 for (int T = 0; T < kWTW; ++T) {
                     const f32x4 gi = *reinterpret_cast<const f32x4*>(&ws.gate[0][0][16 * T + 4 * q]);
@@ -345,7 +348,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
 #pragma unroll
             for (int T = 0; T < kWTW; ++T) wnext[T] = *reinterpret_cast<const f32x4*>(trow + 16 * T * kWH);
             __syncthreads();
-            if (with_theta) {
+            if (lc == 1 ? th_hi : th_lo) {
                 // dW[16 To + i'][16 Ti + j'] = sum_rows sum_streams cot_s[i'][row] x_s[j'][row]: K = the 16 rows,
                 // operands gathered (transposed) from the C/D-layout buffers; unweighted, one 16x16 block per store
                 float aop[kWTW][NS][4];
@@ -412,7 +415,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
                 pz = xq_sum(pz);
                 if (q == 0) part2[wave][m][j] = pz;
             }
-            if (with_theta) {
+            if (th_lo) {
 #pragma unroll
                 for (int T = 0; T < kWTW; ++T) {
                     const int fo = kWF * wave + 16 * T + 4 * q;
@@ -438,35 +441,45 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
 
 // fold the stage slots of an accepted step into the workgroup's running total: total (+)= sum_s wts[s] * slot[sl[s]]
 template <int D>
-__device__ inline void wide_commit(float* __restrict__ region, const int (&sl)[7], const float (&wts)[7], bool first, int tid) {
+__device__ inline void wide_commit(float* __restrict__ region, const int (&sl)[7], const float (&wts)[7], bool first, int tid,
+                                   int part = 0) {
     constexpr int SF = kWideSlotF<D>;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     f32x4* tot = reinterpret_cast<f32x4*>(region + (size_t)kWideTotal * SF);
     constexpr int U = 4;
-    for (int base = tid; base < SF / 4; base += kThreads * U) {
-        f32x4 acc[U];
+    // the slot as two ranges of 16-byte words: [matrix sums | small-parameter sums]; a spread workgroup (part 1 / 2) folds
+    // the half of each it wrote: part 1 the upper halves (W3; small indices >= v3), part 2 the lower ones
+    constexpr int kBig4 = kWideBig / 4, kV34 = kBig4 + WideSmallIdx<D>::v3 / 4;
+    static_assert(WideSmallIdx<D>::v3 % 4 == 0 && kWideBig % 8 == 0, "16-byte ranges");
+    const int lo4[2] = {part == 1 ? kBig4 / 2 : 0, part == 1 ? kV34 : kBig4};
+    const int hi4[2] = {part == 2 ? kBig4 / 2 : kBig4, part == 2 ? kV34 : SF / 4};
+    for (int rg = 0; rg < 2; ++rg) {
+        const int end = hi4[rg];
+        for (int base = lo4[rg] + tid; base < end; base += kThreads * U) {
+            f32x4 acc[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = base + u * kThreads;
-            acc[u] = (!first && i < SF / 4) ? tot[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * kThreads;
+                acc[u] = (!first && i < end) ? tot[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            if (wts[s] != 0.f) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(region + (size_t)sl[s] * SF);
+            for (int s = 0; s < 7; ++s) {
+                if (wts[s] != 0.f) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(region + (size_t)sl[s] * SF);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = base + u * kThreads;
-                    if (i < SF / 4) acc[u] += wts[s] * src[i];
+                    for (int u = 0; u < U; ++u) {
+                        const int i = base + u * kThreads;
+                        if (i < end) acc[u] += wts[s] * src[i];
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = base + u * kThreads;
-            if (i < SF / 4) tot[i] = acc[u];
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * kThreads;
+                if (i < end) tot[i] = acc[u];
+            }
         }
     }
     __syncthreads();
@@ -527,9 +540,12 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
     wide_stage_net(net, a.params, tid);
     zero_slopes(wl, kNW, tid);
     __syncthreads();
-    const long row = (long)blockIdx.x * kRows + j;
+    // a.spread: two workgroups per tile, each keeping half of the d/dtheta sums (kSpreadNote, cnf_split.hip)
+    const int tile = a.spread ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int part = a.spread ? 1 + (int)(blockIdx.x & 1) : 0;
+    const long row = (long)tile * kRows + j;
     const bool valid = row < a.rows;
-    const bool counted = valid && lane < 16 && w == 0;
+    const bool counted = valid && lane < 16 && w == 0 && part != 2;
     const long rr = valid ? row : a.rows - 1;
     WideWaveLds<C>& ws = wl[w];
     float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
@@ -583,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
             with_theta = stage == 6 || wq[stage] != 0.f;
         }
         aug_eval_wide<D, HUTCH>(net, ws, xc, part2, a.params, wt, lane, w, sgn * ti, zz, ee, az, al, sgn, with_theta, f, div, vz,
-                                region + (size_t)slot_i * kWideSlotF<D>);
+                                region + (size_t)slot_i * kWideSlotF<D>, part);
         ++nrun;
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -667,7 +683,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
                     ++nacc;
                     const int sl[7] = {i_first, 1, 2, 3, 4, 5, i_last};
                     const float wts[7] = {wq[0], wq[1], wq[2], wq[3], wq[4], wq[5], wq[6]};
-                    wide_commit<D>(region, sl, wts, nacc == 1, tid);
+                    wide_commit<D>(region, sl, wts, nacc == 1, tid, part);
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
@@ -751,7 +767,8 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
 
 // sum slot `which` of every workgroup region in a fixed order and undo the block layout: out[canonical parameter index]
 template <int D>
-__global__ void wide_reduce_kernel(const float* __restrict__ regions, int nwg, int which, int valid, float* __restrict__ out) {
+__global__ void wide_reduce_kernel(const float* __restrict__ regions, int nwg, int which, int valid, float* __restrict__ out,
+                                   int spread) {
     const ParamLayout L = make_layout(D, kWH);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= L.total) return;
@@ -767,8 +784,9 @@ __global__ void wide_reduce_kernel(const float* __restrict__ regions, int nwg, i
         const int si = p < m1 ? p : (p < m2 ? p - kWH * kWH : p - 2 * kWH * kWH);
         src = kWideBig + si;
     }
-    const size_t stride = (size_t)kWideSlots * kWideSlotF<D>;
-    const float* base = regions + (size_t)which * kWideSlotF<D> + src;
+    // spread launches: tile g's sums are in region 2g (parameters from W3 on) or 2g + 1 (those before W3)
+    const size_t stride = (size_t)(spread ? 2 : 1) * kWideSlots * kWideSlotF<D>;
+    const float* base = regions + (size_t)which * kWideSlotF<D> + src + (spread && p < m2 ? (size_t)kWideSlots * kWideSlotF<D> : 0);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int g = 0;
     for (; g + 3 < nwg; g += 4) {
@@ -783,7 +801,8 @@ __global__ void wide_reduce_kernel(const float* __restrict__ regions, int nwg, i
 
 // ---- launchers --------------------------------------------------------------------------------------------------------
 size_t wide_bwd_workspace_floats(int D, long rows) {
-    const long nwg = (rows + kRows - 1) / kRows;
+    long nwg = (rows + kRows - 1) / kRows;
+    if (2 * nwg <= kMaxWG) nwg *= 2;   // room for a CNF_FLAG_SPREAD launch
     const size_t sf = D == 1 ? (size_t)kWideSlotF<1> : (size_t)kWideSlotF<2>;
     return (size_t)2 * kWH * kWH + (size_t)nwg * kWideSlots * sf;
 }
@@ -802,13 +821,13 @@ static hipError_t wide_bwd_t(const SolveArgs& a0, float* ws_floats, hipStream_t 
     if (err != hipSuccess) return err;
     const int grid = (int)((a.rows + kRows - 1) / kRows);
     dbg_timing_begin(s);
-    hipLaunchKernelGGL((wide_bwd_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a, (const float*)wt);
+    hipLaunchKernelGGL((wide_bwd_kernel<D, HUTCH>), dim3(a.spread ? 2 * grid : grid), dim3(kThreads), 0, s, a, (const float*)wt);
     dbg_timing_end(s);
     err = hipGetLastError();
     if (err != hipSuccess) return err;
     const int P = make_layout(D, kWH).total;
     hipLaunchKernelGGL((wide_reduce_kernel<D>), dim3((P + 255) / 256), dim3(256), 0, s, (const float*)a.slab, grid, kWideTotal, 1,
-                       a.grad_params);
+                       a.grad_params, a.spread);
     return hipGetLastError();
 }
 
@@ -834,7 +853,7 @@ static hipError_t wide_aug_t(const SolveArgs& a0, float* ws_floats, float t, con
     if (err != hipSuccess) return err;
     const int P = make_layout(D, kWH).total;
     hipLaunchKernelGGL((wide_reduce_kernel<D>), dim3((P + 255) / 256), dim3(256), 0, s, (const float*)a.slab, grid, 0, 1,
-                       a.grad_params);
+                       a.grad_params, 0);
     return hipGetLastError();
 }
 

@@ -248,6 +248,32 @@ def test_wide_solve_bwd_matches_oracle_adjoint(dim, hutch, rows):
         off += k
 
 
+@pytest.mark.parametrize("dim,hutch,rows", [(2, False, 2048), (2, False, 100), (1, False, 64), (2, True, 256)])
+def test_wide_spread_adjoint_equals_plain_adjoint(dim, hutch, rows):
+    """CNF_FLAG_SPREAD at width 256: two workgroups per tile, each writing and folding half of the d/dtheta slots; every
+    output identical to the plain launch bit for bit."""
+    nat = _native()
+    g = torch.Generator().manual_seed(29)
+    m = _model(dim, hutch, seed=7, scale=2.0)
+    net = nat.net_desc(dim, 256, 3, hutch)
+    params = _flat(m).to(DEV)
+    x = torch.randn(rows, dim, generator=g).to(DEV)
+    e = torch.randn(rows, dim, generator=g).to(DEV) if hutch else None
+    z1, l1, _ = nat.solve_fwd(net, params, x, None, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5), e)
+    outs = []
+    for flags in (0, nat.FLAG_SPREAD, nat.FLAG_SPREAD):
+        o = nat.make_opts("dopri5", 1e-5, 1e-5, flags=flags)
+        gx, gl0, gp, st = nat.solve_bwd(net, params, z1, l1, z1 / rows, torch.full((rows, 1), 1.0 / rows, device=DEV), 0.0, 0.5, o, e)
+        torch.cuda.synchronize()
+        st = nat.Stats(st)
+        st.raise_for_status()
+        outs.append((gx.clone(), gl0.clone(), gp.clone(), (st.nfe, st.n_accepted, st.n_rejected, st.evals_run)))
+    for other in outs[1:]:
+        assert other[3] == outs[0][3]
+        assert torch.equal(other[0], outs[0][0]) and torch.equal(other[1], outs[0][1]) and torch.equal(other[2], outs[0][2])
+    assert outs[0][2].abs().max().item() > 0
+
+
 def test_wide_fused_training_four_blocks():
     """BASELINE config 4 as a training run in small: 4 stacked blocks of width 256 on gu_num=8 data, FusedTrainStep
     (forward solves, loss, adjoint solves chained through the blocks, Adam): the loss goes down."""
