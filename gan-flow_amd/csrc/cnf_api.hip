@@ -111,11 +111,10 @@ int check_adjoint_rows(const char* who, const CnfNetDesc* n, long rows) {
                     cnf::kRows * cnf::kMaxWG, rows);
     return 0;
 }
-// CNF_FLAG_SPREAD applies to the one-tile-per-workgroup adjoints (hidden 64 and 256) at dim <= 2 when twice the tiles
-// still fit the device
+// CNF_FLAG_SPREAD applies to the one-tile-per-workgroup adjoints (hidden 64 and 256) when twice the tiles still fit the device
 bool can_spread(const CnfNetDesc* n, long rows, int cus) {
     const long tiles = (rows + cnf::kRows - 1) / cnf::kRows;
-    return n->dim <= 2 && use_split(n, rows) && 2 * tiles <= cnf::kMaxWG && 2 * tiles <= cus;
+    return use_split(n, rows) && 2 * tiles <= cnf::kMaxWG && 2 * tiles <= cus;
 }
 long n_slabs(const CnfNetDesc* n, long rows) {
     if (!use_split(n, rows)) return n_wg(rows);

@@ -65,6 +65,6 @@ __device__ inline void stage_wimgT(float* img, const float* __restrict__ p, int 
 }
 
 // sum of the workgroups' gradient slabs in a fixed order (kernel in cnf_split.hip)
-hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s);
+hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s, int split_at = 0);
 
 }  // namespace cnf

@@ -1128,8 +1128,8 @@ __global__ __launch_bounds__(256) void reduce_slab_split_kernel(const float* __r
     if (wv == 0 && p < P) out[p] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, slab, nwg, P, out, 0);
+hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s, int split_at) {
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, slab, nwg, P, out, split_at);
     return hipGetLastError();
 }
 

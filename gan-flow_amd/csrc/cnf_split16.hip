@@ -382,7 +382,10 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
                                            const f32x4& w1Timg, const f32x4& w4Timg, int lane, int wave, float t,
                                            const f32x4& z4, const f32x4& e4, const f32x4& az4, float al, float w,
                                            bool with_theta, f32x4& f4, float& div, f32x4& vz4, BigAccS& acc, f32x4& gw1,
-                                           f32x4& gw4) {
+                                           f32x4& gw4, int part) {
+    // part (CNF_FLAG_SPREAD, kSpreadNote in cnf_split.hip): 0 = all d/dtheta sums, 1 = W3, layer-3 vectors, W4, layer-4
+    // vectors, 2 = W1, layer-1/2 vectors, W2
+    const bool th_hi = with_theta && part != 2, th_lo = with_theta && part != 1;
     const int q = lane >> 4, j = lane & 15, qq = j & 3;
     const int fo = 16 * wave + 4 * q;
     const int pos = (j & 3) * 4 + (j >> 2);
@@ -413,7 +416,7 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
             act[1][r] = (1.0f - x * x) * g[r] * au[r];
         }
     }
-    if (with_theta) {
+    if (th_lo) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sb.tZ[0][(4 * q + r) * kRows + pos] = z4[r];
     }
@@ -489,7 +492,7 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
             cot[0] = mfma16(w4Timg[r], ubar[r], cot[0]);
             cot[1] = mfma16(w4Timg[r], Ubar[r], cot[1]);
         }
-        if (with_theta) {
+        if (th_hi) {
             // dW4[m][feature] = sum_rows (ubar_m x + Ubar_m X): K = the 16 rows, both operands transposed through LDS
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -554,8 +557,8 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
             s2[r] = fmaf(pre, ub[L][r], Pb * Uk);
             cot[0][r] = g[r] * pre;
         }
-        if (with_theta) {
-            if (l < 1) issue_dw(l + 1);   // the previous layer's outer products, next to this vector work
+        if (l < 1 && (l == 0 ? th_hi : th_lo)) issue_dw(l + 1);   // the previous layer's outer products, next to this vector work
+        if (L == 2 ? th_hi : th_lo) {
             float st, gt;
             reduce8(s1, s2, b0, b1, st, gt);
             const float gs = b1 ? (b0 ? g[3] : g[2]) : (b0 ? g[1] : g[0]);
@@ -568,7 +571,7 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
             const int buf = 1 - lc;   // layer 3 publishes through buffer 0, layer 2 through buffer 1
 #pragma unroll
             for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
-            if (with_theta) {
+            if (lc == 1 ? th_hi : th_lo) {
                 const f32x4 gi = *reinterpret_cast<const f32x4*>(&sb.gate[L - 1][0][fo]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -600,7 +603,7 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
 #pragma unroll
             for (int r = 0; r < 4; ++r) pz = mfma16(w1Timg[r], cot[0][r], pz);
             *reinterpret_cast<f32x4*>(&xc.part[wave][0][lane][0]) = pz;
-            if (with_theta) {
+            if (th_lo) {
                 // dW1[feature][m] = sum_rows (cot z_m + tangent cotangent e_m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -625,17 +628,19 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
 
 // accepted step: the workgroup's sums go into its slab (stored, not added, by the first one: no zeroing pass needed)
 __device__ inline void commit16(Bwd16Lds& sb, const BigAccS& acc, const f32x4& gw1, const f32x4& gw4, float* __restrict__ slab_wg,
-                                int tid, bool first) {
+                                int tid, bool first, int part) {
     const ParamLayout L = make_layout(kD, kH);
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int i_lo = part == 1 ? 8 * kH : 0, i_hi = part == 2 ? 8 * kH : kSm16;   // layer-1/2 vectors | layer-3/4 vectors
     __syncthreads();
-    for (int i = tid; i < kSm16; i += kThreads) {
+    for (int i = i_lo + tid; i < i_hi; i += kThreads) {
         const int canon = i < kSmV ? L.b(i / (4 * kH)) + i % (4 * kH) : L.b(3) + (i - kSmV);
         float* dst = &slab_wg[canon];
         *dst = (first ? 0.f : *dst) + sb.small[i];
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l)
+        if (part == 0 || part == 2 - l)
 #pragma unroll
         for (int Ti = 0; Ti < 4; ++Ti)
 #pragma unroll
@@ -645,10 +650,14 @@ __device__ inline void commit16(Bwd16Lds& sb, const BigAccS& acc, const f32x4& g
             }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float* d1 = &slab_wg[L.w(0) + (16 * w + 4 * q + r) * kD + j];
-        *d1 = (first ? 0.f : *d1) + gw1[r];
-        float* d4 = &slab_wg[L.w(3) + (4 * q + r) * kH + 16 * w + j];
-        *d4 = (first ? 0.f : *d4) + gw4[r];
+        if (part != 1) {
+            float* d1 = &slab_wg[L.w(0) + (16 * w + 4 * q + r) * kD + j];
+            *d1 = (first ? 0.f : *d1) + gw1[r];
+        }
+        if (part != 2) {
+            float* d4 = &slab_wg[L.w(3) + (4 * q + r) * kH + 16 * w + j];
+            *d4 = (first ? 0.f : *d4) + gw4[r];
+        }
     }
     __syncthreads();
 }
@@ -674,9 +683,11 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
         w1Timg[r] = a.params[L.w(0) + (16 * w + 4 * q + r) * kD + j];
         w4Timg[r] = a.params[L.w(3) + (4 * q + r) * kH + 16 * w + j];
     }
-    const long row = (long)blockIdx.x * kRows + j;
+    const int tile = a.spread ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;   // kSpreadNote, cnf_split.hip
+    const int part = a.spread ? 1 + (int)(blockIdx.x & 1) : 0;
+    const long row = (long)tile * kRows + j;
     const bool valid = row < a.rows;
-    const bool cz = valid && w == 0;
+    const bool cz = valid && w == 0 && part != 2;
     const bool cl = cz && q == 0;
     const long rr = valid ? row : a.rows - 1;
     float* slab = a.slab + (size_t)blockIdx.x * L.total;
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
         const float wst = phase == PH_STAGE ? sb.wq[stage] : 0.f;
         const bool with_theta = wst != 0.f;
         aug_eval16(net, sb, xc, w1img, w4img, w1Timg, w4Timg, lane, w, sgn * ti, z4, e4, az4, al, sgn * wst, with_theta, f4, div,
-                   vz4, acc, gw1, gw4);
+                   vz4, acc, gw1, gw4, part);
         ++nrun;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -811,7 +822,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
                 const bool accept = (rz <= 1.f) && (rl <= 1.f);
                 if (accept) {
                     ++nacc;
-                    commit16(sb, acc, gw1, gw4, slab, tid, nacc == 1);
+                    commit16(sb, acc, gw1, gw4, slab, tid, nacc == 1, part);
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
                     for (int c = 0; c < kCA; ++c) y0[c] = y1[c];
@@ -903,11 +914,12 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
 hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
     dbg_timing_begin(s);
-    hipLaunchKernelGGL(dopri5_bwd_split16_kernel, dim3(grid), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(dopri5_bwd_split16_kernel, dim3(a.spread ? 2 * grid : grid), dim3(kThreads), 0, s, a);
     dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
-    return launch_reduce_slab(a.slab, grid, make_layout(kD, kH).total, a.grad_params, s);
+    const ParamLayout L = make_layout(kD, kH);
+    return launch_reduce_slab(a.slab, grid, L.total, a.grad_params, s, a.spread ? L.w(2) : 0);
 }
 
 hipError_t launch_split16_fwd(const SolveArgs& a, hipStream_t s) {

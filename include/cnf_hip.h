@@ -68,7 +68,7 @@ typedef struct CnfSolverOpts {
  * does not apply: rk4, tile-local control, more than 4096 rows.                                            */
 enum { CNF_FLAG_CLEAN = 1, CNF_FLAG_SPREAD = 2 };
 
-/* CNF_FLAG_SPREAD (cnf_solve_bwd, dim <= 2, at most half as many 16-row tiles as the device has
+/* CNF_FLAG_SPREAD (cnf_solve_bwd, at most half as many 16-row tiles as the device has
  * compute units -- 2048 rows on an MI355X; ignored otherwise): the adjoint runs TWO workgroups per tile.  Both
  * integrate the tile identically; each keeps half of the parameter-gradient sums, which shortens every augmented
  * evaluation.  Results are those of an unflagged call (same sums, added in the same order).  The launch then occupies

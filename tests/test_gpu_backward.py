@@ -318,7 +318,7 @@ def test_flag_clean_calls_match_zeroing_calls(dim, hidden, rows):
 
 
 @pytest.mark.parametrize("dim,hutch,rows", [(2, False, 2048), (2, False, 100), (1, False, 1000), (2, True, 256), (2, False, 1),
-                                            (2, False, 2064)])
+                                            (2, False, 2064), (16, True, 2048), (16, True, 50)])
 def test_spread_adjoint_equals_plain_adjoint(dim, hutch, rows):
     """CNF_FLAG_SPREAD (include/cnf_hip.h): two workgroups per 16-row tile, each keeping half of the d/dtheta sums.  The
     arithmetic per tile and the order of the additions over tiles are those of the plain launch, so everything the call
