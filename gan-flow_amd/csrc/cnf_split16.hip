@@ -366,7 +366,8 @@ struct alignas(16) Bwd16Lds {
     float tX[kNW][2][16 * kRows];       // per wave: its tile of the last hidden layer's output, transposed (dW4's B operand)
     float tU[2][16 * kRows];            // weighted cotangents of the 16 outputs, transposed (dW4's A operand)
     float tZ[2][16 * kRows];            // [0] z, [1] e, transposed (dW1's B operands)
-    float small[kSm16];                 // d/dtheta of the vector parameters, weighted sum of the attempt
+    float small[3][kSm16];              // d/dtheta of the vector parameters: [0] weighted sum of the attempt, [1], [2] the
+                                        // unweighted sums of the first / seventh stage (FSAL, kFsalTheta in cnf_split.hip)
     float wq[8];
     // one copy for the four waves (they hold identical values; readers and the next evaluation's writers are
     // separated by workgroup barriers), as are tU and tZ
@@ -381,8 +382,11 @@ struct alignas(16) Bwd16Lds {
 __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg16& xc, const f32x4& w1img, const f32x4& w4img,
                                            const f32x4& w1Timg, const f32x4& w4Timg, int lane, int wave, float t,
                                            const f32x4& z4, const f32x4& e4, const f32x4& az4, float al, float w,
-                                           bool with_theta, f32x4& f4, float& div, f32x4& vz4, BigAccS& acc, f32x4& gw1,
-                                           f32x4& gw4, int part) {
+                                           bool with_theta, f32x4& f4, float& div, f32x4& vz4, f32x4 (&dw2)[4],
+                                           f32x4 (&dw3)[4], f32x4& gw1, f32x4& gw4, int part, int small_base) {
+    // dw2 / dw3: sums for the two 64 x 64 matrices; gw1 / gw4: for W1 / W4.  In the spread kernel a workgroup owns one of
+    // each pair and the caller passes the same registers for both (the unowned one is never touched: th_hi / th_lo)
+    float* const small = &sb.small[0][0] + small_base;
     // part (CNF_FLAG_SPREAD, kSpreadNote in cnf_split.hip): 0 = all d/dtheta sums, 1 = W3, layer-3 vectors, W4, layer-4
     // vectors, 2 = W1, layer-1/2 vectors, W2
     const bool th_hi = with_theta && part != 2, th_lo = with_theta && part != 1;
@@ -518,7 +522,7 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
                 const float gg = g4[r] * (1.0f - g4[r]);
                 const float val = j < 2 ? s4 : gb;
                 const float fac = j == 0 ? g4[r] : (j == 1 ? t : (j == 2 ? t * gg : gg));
-                if (wave == 0 && j < 4) lds_add(&sb.small[kSmV + j * kD + 4 * q + r], w * fac * val);
+                if (wave == 0 && j < 4) lds_add(&small[kSmV + j * kD + 4 * q + r], w * fac * val);
             }
         }
     }
@@ -534,7 +538,10 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int Ti = 0; Ti < 4; ++Ti) acc.gw[lc][Ti] = mfma16(a4[ks], b4[Ti][ks], acc.gw[lc][Ti]);
+                for (int Ti = 0; Ti < 4; ++Ti) {
+                    if (lc == 0) dw2[Ti] = mfma16(a4[ks], b4[Ti][ks], dw2[Ti]);
+                    else dw3[Ti] = mfma16(a4[ks], b4[Ti][ks], dw3[Ti]);
+                }
         }
     };
 
@@ -564,7 +571,7 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
             const float gs = b1 ? (b0 ? g[3] : g[2]) : (b0 ? g[1] : g[0]);
             const float gg = gs * (1.0f - gs);
             const float fac = fmaf(gg, km23, fmaf(km0, gs, km1t));
-            lds_add(&sb.small[L * 4 * kH + kind * kH + fo + qq], w * fac * (kind < 2 ? st : gt));
+            lds_add(&small[L * 4 * kH + kind * kH + fo + qq], w * fac * (kind < 2 ? st : gt));
         }
         if (l >= 0) {
             const int lc = l < 0 ? 0 : l;
@@ -627,8 +634,40 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
 }
 
 // accepted step: the workgroup's sums go into its slab (stored, not added, by the first one: no zeroing pass needed)
-__device__ inline void commit16(Bwd16Lds& sb, const BigAccS& acc, const f32x4& gw1, const f32x4& gw4, float* __restrict__ slab_wg,
-                                int tid, bool first, int part) {
+// Sums of one evaluation (or of one attempt): the two 64 x 64 matrices, this lane's entries of dW1 and dW4.  HALF (the
+// spread kernel): a workgroup keeps ONE matrix and ONE of dW1 / dW4 (part 1: W3 and W4, part 2: W2 and W1), which is what
+// lets three such sets (the attempt's sums and the two FSAL buffers) fit the register file.
+template <bool HALF>
+struct Acc16 {
+    f32x4 m[HALF ? 1 : 2][4];
+    f32x4 g[HALF ? 1 : 2];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int l = 0; l < (HALF ? 1 : 2); ++l) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[l][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            g[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ f32x4 (&dw(int l))[4] { return m[HALF ? 0 : l]; }
+    __device__ __forceinline__ const f32x4 (&dw(int l) const)[4] { return m[HALF ? 0 : l]; }
+    __device__ __forceinline__ f32x4& thin(int which) { return g[HALF ? 0 : which]; }   // 0: dW1, 1: dW4
+    __device__ __forceinline__ const f32x4& thin(int which) const { return g[HALF ? 0 : which]; }
+};
+
+template <bool HALF>
+__device__ __forceinline__ void swap16(Acc16<HALF>& a, Acc16<HALF>& b) {
+    const Acc16<HALF> t = a;
+    a = b;
+    b = t;
+}
+
+// accepted step: the workgroup's sums go into its slab (stored, not added, by the first one: no zeroing pass needed).
+// FSAL: step sums + w_first * G(first stage) + w_last * G(seventh stage), see commit_step_fsal in cnf_split.hip
+template <bool HALF>
+__device__ inline void commit16(Bwd16Lds& sb, const Acc16<HALF>& A, const Acc16<HALF>& F, const Acc16<HALF>& G, int i_first,
+                                int i_last, float w_first, float w_last, float* __restrict__ slab_wg, int tid, bool first,
+                                int part) {
     const ParamLayout L = make_layout(kD, kH);
     const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
     const int i_lo = part == 1 ? 8 * kH : 0, i_hi = part == 2 ? 8 * kH : kSm16;   // layer-1/2 vectors | layer-3/4 vectors
@@ -636,7 +675,9 @@ __device__ inline void commit16(Bwd16Lds& sb, const BigAccS& acc, const f32x4& g
     for (int i = i_lo + tid; i < i_hi; i += kThreads) {
         const int canon = i < kSmV ? L.b(i / (4 * kH)) + i % (4 * kH) : L.b(3) + (i - kSmV);
         float* dst = &slab_wg[canon];
-        *dst = (first ? 0.f : *dst) + sb.small[i];
+        float v = sb.small[0][i];
+        if (HALF) v = fmaf(w_last, sb.small[i_last][i], fmaf(w_first, sb.small[i_first][i], v));
+        *dst = (first ? 0.f : *dst) + v;
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l)
@@ -646,22 +687,31 @@ __device__ inline void commit16(Bwd16Lds& sb, const BigAccS& acc, const f32x4& g
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float* dst = &slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j];
-                *dst = (first ? 0.f : *dst) + acc.gw[l][Ti][r];
+                float v = A.dw(l)[Ti][r];
+                if (HALF) v = fmaf(w_last, G.dw(l)[Ti][r], fmaf(w_first, F.dw(l)[Ti][r], v));
+                *dst = (first ? 0.f : *dst) + v;
             }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if (part != 1) {
             float* d1 = &slab_wg[L.w(0) + (16 * w + 4 * q + r) * kD + j];
-            *d1 = (first ? 0.f : *d1) + gw1[r];
+            float v = A.thin(0)[r];
+            if (HALF) v = fmaf(w_last, G.thin(0)[r], fmaf(w_first, F.thin(0)[r], v));
+            *d1 = (first ? 0.f : *d1) + v;
         }
         if (part != 2) {
             float* d4 = &slab_wg[L.w(3) + (4 * q + r) * kH + 16 * w + j];
-            *d4 = (first ? 0.f : *d4) + gw4[r];
+            float v = A.thin(1)[r];
+            if (HALF) v = fmaf(w_last, G.thin(1)[r], fmaf(w_first, F.thin(1)[r], v));
+            *d4 = (first ? 0.f : *d4) + v;
         }
     }
     __syncthreads();
 }
 
+// SPREAD: launched with two workgroups per tile (a.spread); half accumulators and FSAL for the theta quadrature (six
+// evaluations per attempt).  Otherwise one workgroup per tile keeps all sums and re-evaluates the first stage (seven).
+template <bool SPREAD>
 __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs a) {
     __shared__ Net16Lds net;
     __shared__ Bwd16Lds sb;
@@ -673,7 +723,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     stage_net16(net, a.params, tid);
     stage_wimgT<kD>(&sb.wimgT[0][0][0][0], a.params, tid);
     for (int i = tid; i < 7 * kCA * 64; i += kThreads) (&sb.kst[0][0][0])[i] = 0.f;
-    for (int i = tid; i < kSm16; i += kThreads) sb.small[i] = 0.f;
+    for (int i = tid; i < 3 * kSm16; i += kThreads) (&sb.small[0][0])[i] = 0.f;
     const ParamLayout L = make_layout(kD, kH);
     const f32x4 w1img = *reinterpret_cast<const f32x4*>(a.params + L.w(0) + (16 * w + j) * kD + 4 * q);
     const f32x4 w4img = *reinterpret_cast<const f32x4*>(a.params + L.w(3) + j * kH + 16 * w + 4 * q);
@@ -683,8 +733,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
         w1Timg[r] = a.params[L.w(0) + (16 * w + 4 * q + r) * kD + j];
         w4Timg[r] = a.params[L.w(3) + (4 * q + r) * kH + 16 * w + j];
     }
-    const int tile = a.spread ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;   // kSpreadNote, cnf_split.hip
-    const int part = a.spread ? 1 + (int)(blockIdx.x & 1) : 0;
+    constexpr bool FSAL = SPREAD;
+    const int tile = SPREAD ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;   // kSpreadNote, cnf_split.hip
+    const int part = SPREAD ? 1 + (int)(blockIdx.x & 1) : 0;
     const long row = (long)tile * kRows + j;
     const bool valid = row < a.rows;
     const bool cz = valid && w == 0 && part != 2;
@@ -725,9 +776,11 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     int nacc = 0, nrej = 0, status = 0, nrun = 0;
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[kCE];
-    BigAccS acc;
+    Acc16<SPREAD> acc, gfirst, glast;   // acc: the attempt's weighted sums; gfirst / glast: unweighted sums of its first / seventh stage
     acc.zero();
-    f32x4 gw1 = {0.f, 0.f, 0.f, 0.f}, gw4 = {0.f, 0.f, 0.f, 0.f};
+    gfirst.zero();
+    glast.zero();
+    int i_first = 1, i_last = 2;   // which of sb.small[1], sb.small[2] holds the first / seventh stage's sums
 
     for (;;) {
         f32x4 z4, az4, f4, vz4;
@@ -738,10 +791,20 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
             z4[r] = yi[r];
             az4[r] = yi[5 + r];
         }
-        const float wst = phase == PH_STAGE ? sb.wq[stage] : 0.f;
+        // which d/dtheta sum this evaluation feeds: the attempt's weighted quadrature, or an unweighted FSAL buffer
+        const bool to_first = FSAL && phase == PH_F0;
+        const bool to_last = FSAL && phase == PH_STAGE && stage == 6;
+        const float wst = (to_first || to_last) ? 1.f : (phase == PH_STAGE ? sb.wq[stage] : 0.f);
         const bool with_theta = wst != 0.f;
+        // one inlined copy of the evaluation, always accumulating into `acc`: an FSAL evaluation trades places with its
+        // (zeroed) buffer before and after
+        if (to_first) { gfirst.zero(); swap16(acc, gfirst); }
+        if (to_last) { glast.zero(); swap16(acc, glast); }
         aug_eval16(net, sb, xc, w1img, w4img, w1Timg, w4Timg, lane, w, sgn * ti, z4, e4, az4, al, sgn * wst, with_theta, f4, div,
-                   vz4, acc, gw1, gw4, part);
+                   vz4, acc.dw(0), acc.dw(1), acc.thin(0), acc.thin(1), part,
+                   to_first ? i_first * kSm16 : (to_last ? i_last * kSm16 : 0));
+        if (to_first) swap16(acc, gfirst);
+        if (to_last) swap16(acc, glast);
         ++nrun;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -822,10 +885,18 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
                 const bool accept = (rz <= 1.f) && (rl <= 1.f);
                 if (accept) {
                     ++nacc;
-                    commit16(sb, acc, gw1, gw4, slab, tid, nacc == 1, part);
+                    commit16(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid, nacc == 1, part);
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
                     for (int c = 0; c < kCA; ++c) y0[c] = y1[c];
+                    if (FSAL) {
+#pragma unroll
+                        for (int c = 0; c < kCA; ++c) sb.kst[0][c][lane] = k[c];   // the seventh stage is the next step's first
+                        gfirst = glast;
+                        const int t_ = i_first;
+                        i_first = i_last;
+                        i_last = t_;
+                    }
                     tau = tau + dt;
                 } else {
                     ++nrej;
@@ -839,13 +910,14 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
             if (nacc + nrej >= a.max_steps) { status = CNF_ERR_MAX_STEPS; break; }
             dtf = (float)dt;
             t0f = (float)tau;
-            stage = 0;
+            stage = FSAL ? 1 : 0;
             phase = PH_STAGE;
             acc.zero();
-            gw1 = f32x4{0.f, 0.f, 0.f, 0.f};
-            gw4 = f32x4{0.f, 0.f, 0.f, 0.f};
             __syncthreads();   // every wave is past its last read of small / wq of the previous attempt
-            for (int i = tid; i < kSm16; i += kThreads) sb.small[i] = 0.f;
+            for (int i = tid; i < kSm16; i += kThreads) {
+                sb.small[0][i] = 0.f;
+                if (FSAL) sb.small[i_last][i] = 0.f;
+            }
             if (tid < 7) {
                 const int s = tid;
                 float v;
@@ -914,7 +986,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
 hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
     dbg_timing_begin(s);
-    hipLaunchKernelGGL(dopri5_bwd_split16_kernel, dim3(a.spread ? 2 * grid : grid), dim3(kThreads), 0, s, a);
+    if (a.spread) hipLaunchKernelGGL(dopri5_bwd_split16_kernel<true>, dim3(2 * grid), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL(dopri5_bwd_split16_kernel<false>, dim3(grid), dim3(kThreads), 0, s, a);
     dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;

@@ -322,7 +322,7 @@ def test_flag_clean_calls_match_zeroing_calls(dim, hidden, rows):
 def test_spread_adjoint_equals_plain_adjoint(dim, hutch, rows):
     """CNF_FLAG_SPREAD (include/cnf_hip.h): two workgroups per 16-row tile, each keeping half of the d/dtheta sums.  The
     arithmetic per tile and the order of the additions over tiles are those of the plain launch, so everything the call
-    returns is identical bit for bit (2064 rows = 129 tiles do not fit twice: the flag is ignored there)."""
+    returns is identical bit for bit (2064 rows = 129 tiles do not fit twice: the flag is ignored there; d = 16: see below)."""
     nat = _native()
     g = torch.Generator().manual_seed(31)
     m = oracle_random_model(dim, seed=9, divergence_fn="approximate" if hutch else "brute_force", scale=2.0)
@@ -342,8 +342,16 @@ def test_spread_adjoint_equals_plain_adjoint(dim, hutch, rows):
         st = nat.Stats(st)
         st.raise_for_status()
         outs.append((gx.clone(), gl0.clone(), gp.clone(), (st.nfe, st.n_accepted, st.n_rejected, st.evals_run)))
-    for other in outs[1:]:
-        assert other[3] == outs[0][3]
-        assert torch.equal(other[0], outs[0][0]) and torch.equal(other[1], outs[0][1])
-        assert torch.equal(other[2], outs[0][2])
+    assert outs[2][3] == outs[1][3] and all(torch.equal(u, v) for u, v in zip(outs[1][:3], outs[2][:3]))   # repeatable
+    if dim == 16:
+        # d = 16: the spread kernel also reuses the seventh stage's d/dtheta as the next step's first (FSAL: six evaluations
+        # per attempt, its half-size accumulators leave room for the buffers); the plain kernel re-evaluates it at a time
+        # that may differ in the last bit -> same steps, gradients equal to rounding
+        assert outs[1][3][:3] == outs[0][3][:3]
+        assert outs[1][3][3] == outs[1][3][0] and outs[0][3][3] == outs[0][3][0] + outs[0][3][1] + outs[0][3][2]
+        assert rel_err(outs[1][0], outs[0][0]) < 1e-5 and torch.equal(outs[1][1], outs[0][1])
+        assert rel_err(outs[1][2], outs[0][2]) < 1e-5
+    else:
+        assert outs[1][3] == outs[0][3]
+        assert all(torch.equal(u, v) for u, v in zip(outs[1][:3], outs[0][:3]))
     assert outs[0][2].abs().max().item() > 0
