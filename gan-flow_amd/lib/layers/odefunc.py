@@ -4,6 +4,7 @@ divergence lives in gan-flow_amd/csrc (forward-mode tangents on the matrix cores
 parameters, the evaluation counter and the Hutchinson probe, and describe the net to the kernels."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import _native
 from .diffeq_layers.basic import LAYER_TYPES, ConcatSquashLinear
@@ -24,7 +25,12 @@ class ODEnet(nn.Module):
     """dim -> hidden_dims -> dim stack of time-conditioned linear layers with tanh between (not after) them.
     layer_type: 'concatsquash' (the reference's runs and checkpoints) or one of its special cases 'ignore', 'concat',
     'concatcoord', 'concat_v2', 'squash' (diffeq_layers/basic.py); 'hyper' and 'blend' have time-dependent weight
-    matrices and are not built."""
+    matrices and are not built.
+
+    hidden_dims: three hidden layers.  The kernels are built for widths 64 and 256; any other widths (equal or not, up
+    to 256) are presented to them zero-padded to the next kernel width (kernel_hidden): a padded feature has zero
+    weights, bias and time terms, so it is exactly tanh(0) = 0 in every layer and stream and contributes exact zeros
+    to the sums that follow -- the padded net IS the narrow net.  Autograd slices the kernels' gradient back."""
 
     def __init__(self, hidden_dims, input_shape, strides=None, conv=False, layer_type="concatsquash",
                  nonlinearity="tanh", num_squeeze=0):
@@ -42,19 +48,43 @@ class ODEnet(nn.Module):
     def dims(self):
         return (self.layers[0].dim_in,) + tuple(l.dim_out for l in self.layers)
 
+    KERNEL_WIDTHS = (64, 256)
+
+    def kernel_hidden(self):
+        """The hidden width the kernels run this net at: the smallest built width that holds every hidden layer."""
+        hidden = self.dims[1:-1]
+        for w in self.KERNEL_WIDTHS:
+            if max(hidden) <= w:
+                return w
+        raise NotImplementedError("the HIP path is built for hidden widths up to %d (got %s)" % (self.KERNEL_WIDTHS[-1], hidden))
+
+    def is_padded(self):
+        return any(h != self.kernel_hidden() for h in self.dims[1:-1])
+
     def flat_parameters(self):
         """The parameter vector in the order include/cnf_hip.h documents: per layer W, b, w_hb, w_g, b_g (for
-        concatsquash that is self.parameters() order; the other layer types fill in constants, see basic.py)."""
-        return torch.cat([p.reshape(-1) for layer in self.layers for p in layer.kernel_slices()])
+        concatsquash that is self.parameters() order; the other layer types fill in constants, see basic.py), hidden
+        widths zero-padded to kernel_hidden()."""
+        if not self.is_padded():
+            return torch.cat([p.reshape(-1) for layer in self.layers for p in layer.kernel_slices()])
+        hk, last, parts = self.kernel_hidden(), len(self.layers) - 1, []
+        for i, layer in enumerate(self.layers):
+            w, b, w_hb, w_g, b_g = layer.kernel_slices()
+            pad_in = 0 if i == 0 else hk - w.shape[1]
+            pad_out = 0 if i == last else hk - w.shape[0]
+            parts.append(F.pad(w, (0, pad_in, 0, pad_out)).reshape(-1))
+            parts += [F.pad(v.reshape(-1), (0, pad_out)) for v in (b, w_hb, w_g, b_g)]
+        return torch.cat(parts)
 
     def flatten_parameters(self):
         """Move the parameters into ONE contiguous buffer laid out as the kernels read it and make every
         nn.Parameter a view of its slice (names, shapes and state_dict are unchanged).  Returns the buffer: an update
         written to it (gu_ffjord.FusedTrainStep) is an update of the module's parameters.  `.to()` / `.cuda()` /
         load_state_dict(assign=True) re-allocate parameters: call again afterwards (flat_is_current() tells)."""
-        if self.layer_type != "concatsquash":
-            raise NotImplementedError("flatten_parameters (and FusedTrainStep) need layer_type='concatsquash': the other "
-                                      "layer types present constants to the kernels that an in-place optimizer must not touch")
+        if self.layer_type != "concatsquash" or self.is_padded():
+            raise NotImplementedError("flatten_parameters (and FusedTrainStep) need layer_type='concatsquash' and hidden widths "
+                                      "64 or 256: other layer types and padded widths present constants to the kernels that "
+                                      "an in-place optimizer must not touch (train them through autograd: GraphedTrainStep)")
         ps = list(self.parameters())
         flat = torch.cat([p.detach().reshape(-1) for p in ps])
         off = 0
@@ -115,10 +145,7 @@ class ODEfunc(nn.Module):
 
     def net_desc(self):
         dims = self.diffeq.dims
-        hidden = dims[1:-1]
-        if len(set(hidden)) != 1:
-            raise NotImplementedError("the HIP path needs equal hidden widths (got %s)" % (hidden,))
-        return _native.net_desc(dims[0], hidden[0], len(hidden), self.uses_hutchinson())
+        return _native.net_desc(dims[0], self.diffeq.kernel_hidden(), len(dims) - 2, self.uses_hutchinson())
 
     def probe(self, like):
         """Hutchinson noise: drawn once per solve (before_odeint resets it) and reused by the adjoint pass."""

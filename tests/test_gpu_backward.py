@@ -355,3 +355,31 @@ def test_spread_adjoint_equals_plain_adjoint(dim, hutch, rows):
         assert outs[1][3] == outs[0][3]
         assert all(torch.equal(u, v) for u, v in zip(outs[1][:3], outs[0][:3]))
     assert outs[0][2].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("hidden", [(32, 32, 32), (48, 64, 16), (100, 100, 100), (7, 130, 64)])
+def test_other_hidden_widths_run_zero_padded(hidden):
+    """Hidden widths other than 64 / 256 (ODEnet.kernel_hidden): the kernels see the net zero-padded to the next built
+    width; loss, solver steps and the gradients of the real parameters match the oracle at those widths."""
+    from gan_flow_amd import gu_ffjord
+    mo = oracle_random_model(2, seed=17, scale=1.5, hidden_dims=hidden)
+    mo.train()
+    mp = gu_ffjord.build_model(2, dims=hidden)
+    mp.load_state_dict(mo.state_dict())
+    mp = mp.to(DEV).train()
+    net = mp.chain[0].odefunc.odefunc.diffeq
+    assert net.is_padded() and net.kernel_hidden() == (64 if max(hidden) <= 64 else 256)
+    x = torch.randn(300, 2, generator=torch.Generator().manual_seed(2))
+    loss_ref, z_ref, dl_ref, gx_ref, gp_ref, st_ref = _oracle_train_grads(mo, x)
+    xp = x.to(DEV).requires_grad_(True)
+    loss = gu_ffjord.compute_loss(mp, xp)
+    loss.backward()
+    gp = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert gp.numel() == gp_ref.numel()
+    st = mp.chain[0].last_stats
+    assert (st["forward"].n_accepted, st["forward"].n_rejected) == (st_ref["forward"]["n_accepted"], st_ref["forward"]["n_rejected"])
+    assert (st["backward"].n_accepted, st["backward"].n_rejected) == (st_ref["backward"]["n_accepted"], st_ref["backward"]["n_rejected"])
+    assert abs(loss.item() - loss_ref) < 1e-4
+    assert rel_err(gp, gp_ref) < 2e-4 and rel_err(xp.grad, gx_ref) < 2e-4
+    with pytest.raises(NotImplementedError):
+        gu_ffjord.FusedTrainStep(mp, xp.detach(), graph=False)

@@ -196,3 +196,30 @@ def test_layer_types_present_themselves_as_concatsquash(layer_type):
             net.flatten_parameters()
     with pytest.raises(NotImplementedError):
         ODEnet((64, 64, 64), (2,), layer_type="blend")
+
+
+def test_padded_hidden_widths_describe_the_same_net():
+    """ODEnet.flat_parameters() for hidden widths the kernels are not built for: zero-padded to width 64 in the kernels'
+    layout; loaded into a real 64-wide net it evaluates to the narrow net's output, and gradients come back sliced."""
+    from gan_flow_amd.lib.layers.odefunc import ODEnet
+    torch.manual_seed(3)
+    narrow = ODEnet((32, 48, 16), (2,))
+    assert narrow.is_padded() and narrow.kernel_hidden() == 64
+    flat = narrow.flat_parameters()
+    wide = ODEnet((64, 64, 64), (2,))
+    assert not wide.is_padded() and flat.numel() == wide.flat_parameters().numel() == 9224
+    off = 0
+    with torch.no_grad():
+        for p in wide.parameters():
+            p.copy_(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+    y = torch.randn(50, 2)
+    assert torch.allclose(wide(0.3, y), narrow(0.3, y), atol=1e-6)
+    g = torch.randn_like(flat)
+    (flat * g).sum().backward()
+    w2 = narrow.layers[1]._layer.weight                      # (48, 32) inside the 64 x 64 block that follows layer 1
+    blk = g[2 * 64 + 4 * 64: 2 * 64 + 4 * 64 + 64 * 64].view(64, 64)
+    assert torch.equal(w2.grad, blk[:48, :32])
+    assert ODEnet((100, 100, 100), (2,)).kernel_hidden() == 256
+    with pytest.raises(NotImplementedError):
+        ODEnet((300, 64, 64), (2,)).kernel_hidden()
