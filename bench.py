@@ -177,7 +177,7 @@ def main():
                                "rtol=atol=1e-5, T=0.5, exact divergence, adjoint backward, Adam; weights from seed-1 "
                                "init (first %d iterations of training)" % (args.batch, args.warmup + args.steps),
                    "global_batch": args.batch * world, "parallelism": "independent trial per GPU (replicas only)",
-                   "launch": {"fused": "4 library kernels (fwd solve, nll loss, adjoint solve + slab reduction, Adam), one hipGraph replay per iteration",
+                   "launch": {"fused": "3 library kernels (fwd solve; adjoint solve with the NLL cotangents and loss formed inside, two workgroups per tile; gradient-slab sum + Adam), one hipGraph replay per iteration",
                               "graph": "autograd + torch.optim.Adam loop, one hipGraph replay per iteration",
                               "eager": "autograd + torch.optim.Adam loop, eager"}[args.mode],
                    "mean_nfe_forward": round(nfe_f / args.steps, 1), "mean_nfe_backward": round(nfe_b / args.steps, 1)},

@@ -39,7 +39,7 @@ STATUS_MESSAGES = {
     4: "grid-wide reduction timed out inside the solver kernel",
 }
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
-           "cnf_eval_aug", "cnf_solve_bwd", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
+           "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
            "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms")
 
 
@@ -73,6 +73,9 @@ def load_library():
     lib.cnf_eval_aug.argtypes = [ND, P, F, P, P, P, P, I64, P, P, P, P, VP, SZ, VP]
     lib.cnf_solve_bwd.restype = ctypes.c_int
     lib.cnf_solve_bwd.argtypes = [ND, P, P, P, P, P, P, I64, F, F, SO, P, P, P, VP, SZ, P, VP]
+    lib.cnf_solve_bwd_train.restype = ctypes.c_int
+    lib.cnf_solve_bwd_train.argtypes = [ND, P, P, P, P, P, P, I64, F, F, SO, P, P, P, P, P, P, P, ctypes.POINTER(CnfAdamOpts),
+                                        VP, SZ, P, VP]
     lib.cnf_nll_loss.restype = ctypes.c_int
     lib.cnf_nll_loss.argtypes = [P, P, I64, ctypes.c_int32, P, P, P, VP]
     lib.cnf_adam_step.restype = ctypes.c_int
@@ -262,6 +265,42 @@ def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None,
                                  _ptr(grad_logp1), rows, float(t0), float(t1), ctypes.byref(opts), _ptr(gx), _ptr(gl),
                                  _ptr(gp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
     return gx, gl, gp, stats
+
+
+def solve_bwd_train(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, exp_avg, exp_avg_sq, state, e=None, stats=None,
+                    workspace=None, want_grad_params=False, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """cnf_solve_bwd_train: adjoint pass + Adam update of `params` (in place) in two kernels.  grad_z1 = grad_logp1 = None:
+    the cotangents of the flow's NLL, formed in the kernel; the loss is returned.
+    Returns (grad_x, grad_logp0, grad_params or None, loss[1] or None, stats_words)."""
+    lib = load_library()
+    z1 = _dev(z1, "z1")
+    rows = z1.shape[0]
+    n = param_count(net)
+    for name, t in (("params", params), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if _dev(t, name, (n,)).data_ptr() != t.data_ptr():
+            raise CnfError("%s must be contiguous" % name)
+    if not (torch.is_tensor(state) and state.is_cuda and state.dtype == torch.int32 and state.numel() == 2):
+        raise CnfError("state must be 2 int32 words on the HIP device")
+    logp1 = _dev(logp1, "logp1", (rows, 1))
+    nll = grad_z1 is None
+    if nll and grad_logp1 is not None:
+        raise CnfError("grad_z1=None selects the NLL cotangents: grad_logp1 must be None too")
+    grad_z1 = None if nll else _dev(grad_z1, "grad_z1", z1.shape)
+    grad_logp1 = None if nll else _dev(grad_logp1, "grad_logp1", (rows, 1))
+    e = _dev(e, "e", z1.shape) if e is not None else None
+    gx = torch.empty_like(z1)
+    gl = torch.empty_like(logp1)
+    gp = torch.empty_like(params) if want_grad_params else None
+    loss = torch.empty(1, dtype=torch.float32, device=z1.device) if nll else None
+    stats = _stats_block(stats, z1.device)
+    o = CnfAdamOpts(float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay))
+    with torch.cuda.device(z1.device):
+        ws = _workspace(lib, net, rows, z1.device) if workspace is None else _own_workspace(lib, net, rows, workspace)
+        _check(lib.cnf_solve_bwd_train(ctypes.byref(net), _ptr(params), _ptr(z1), _ptr(logp1), _ptr(e), _ptr(grad_z1),
+                                       _ptr(grad_logp1), rows, float(t0), float(t1), ctypes.byref(opts), _ptr(gx), _ptr(gl),
+                                       _ptr(gp), _ptr(loss), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(state), ctypes.byref(o),
+                                       _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
+    return gx, gl, gp, loss, stats
 
 
 def nll_loss(z, delta_logp, want_grads=True):

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "cnf_launch.h"
+#include "cnf_split.h"
 
 namespace cnf {
 hipError_t launch_eval_aug(int D, bool hutch, const SolveArgs& a, float t, const float* z, const float* a_z,
@@ -300,23 +301,35 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
     return 0;
 }
 
-int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, const float* logp1, const float* e,
-                  const float* grad_z1, const float* grad_logp1, int64_t rows, float t0, float t1,
-                  const CnfSolverOpts* opts, float* grad_x, float* grad_logp0, float* grad_params, void* workspace,
-                  size_t workspace_bytes, CnfStats* stats, void* stream) {
-    cnf::SolveArgs a;
+}  // extern "C"
+
+namespace {
+// cnf_solve_bwd and the solve half of cnf_solve_bwd_train.  train: the cotangents may be left out (loss_out set:
+// the kernel forms those of the NLL itself) and the gradient slabs stay in the workspace for launch_adam_slabs.
+int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const float* params, const float* z1, const float* logp1,
+                   const float* e, const float* grad_z1, const float* grad_logp1, int64_t rows, float t0, float t1,
+                   const CnfSolverOpts* opts, float* grad_x, float* grad_logp0, float* grad_params, float* loss_out,
+                   void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream, cnf::SolveArgs& a) {
     bool global;
     if (net && supported(net) && is_wide(net) && rows > (int64_t)cnf::kRows * cnf::kMaxWG)
-        return fail("cnf_solve_bwd: the adjoint at hidden width 256 supports at most %d rows per call (got %ld)",
+        return fail("%s: the adjoint at hidden width 256 supports at most %d rows per call (got %ld)", who,
                     cnf::kRows * cnf::kMaxWG, (long)rows);
-    if (fill_common("cnf_solve_bwd", net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
-    if (!z1 || !logp1 || !grad_z1 || !grad_logp1 || !grad_x || !grad_logp0 || !grad_params)
-        return fail("cnf_solve_bwd: NULL pointer");
-    if (opts->solver != CNF_SOLVER_DOPRI5) return fail("cnf_solve_bwd: the adjoint pass is built for dopri5 only");
-    if (!global) return fail("cnf_solve_bwd: the adjoint pass needs batch-global step control (tile_rows = 0)");
+    if (fill_common(who, net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
+    const bool nll = train && !grad_z1;
+    if (!z1 || !logp1 || !grad_x || !grad_logp0 || (!train && !grad_params)) return fail("%s: NULL pointer", who);
+    if (!nll && (!grad_z1 || !grad_logp1)) return fail("%s: NULL pointer (grad_z1 / grad_logp1)", who);
+    if (nll && (grad_logp1 || !loss_out))
+        return fail("%s: grad_z1 == NULL asks for the NLL cotangents: grad_logp1 must be NULL too and loss_out set", who);
+    if (train && (is_wide(net) || !use_split(net, rows)))
+        return fail("%s: built for hidden width 64 and at most %d rows (got hidden %d, %ld rows); use cnf_nll_loss, "
+                    "cnf_solve_bwd and cnf_adam_step", who, cnf::kRows * cnf::kMaxWG, net->hidden, (long)rows);
+    if (opts->solver != CNF_SOLVER_DOPRI5) return fail("%s: the adjoint pass is built for dopri5 only", who);
+    if (!global) return fail("%s: the adjoint pass needs batch-global step control (tile_rows = 0)", who);
     const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
-    if (hutch && !e) return fail("cnf_solve_bwd: Hutchinson divergence needs the probe e");
-    if (check_adjoint_rows("cnf_solve_bwd", net, rows)) return 1;
+    if (hutch && !e) return fail("%s: Hutchinson divergence needs the probe e", who);
+    if (check_adjoint_rows(who, net, rows)) return 1;
+    a.loss_out = nll ? loss_out : nullptr;
+    a.keep_slabs = train ? 1 : 0;
     a.x = z1;
     a.logp0 = logp1;
     a.e = e;
@@ -328,14 +341,14 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     a.spread = (opts->flags & CNF_FLAG_SPREAD) && can_spread(net, rows, device_cus()) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (is_wide(net)) {
-        if (((uintptr_t)params & 15) != 0) return fail("cnf_solve_bwd: params must be 16-byte aligned for hidden width 256");
+        if (((uintptr_t)params & 15) != 0) return fail("%s: params must be 16-byte aligned for hidden width 256", who);
         hipError_t werr = hipSuccess;
         if (!(opts->flags & CNF_FLAG_CLEAN)) {
             werr = hipMemsetAsync(workspace, 0, kGranBytes, s);   // the gradient slots are written before they are read
             if (werr == hipSuccess) werr = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
         }
         if (werr == hipSuccess) werr = cnf::launch_wide_bwd(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), s);
-        if (werr != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(werr));
+        if (werr != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(werr));
         return 0;
     }
     hipError_t err = hipSuccess;
@@ -350,7 +363,42 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
         if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
     }
     if (err == hipSuccess) err = use_split(net, rows) ? cnf::launch_split_bwd(net->dim, hutch, a, s) : cnf::launch_solve_bwd(net->dim, hutch, a, s);
-    if (err != hipSuccess) return fail("cnf_solve_bwd: launch failed: %s", hipGetErrorString(err));
+    if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, const float* logp1, const float* e,
+                  const float* grad_z1, const float* grad_logp1, int64_t rows, float t0, float t1,
+                  const CnfSolverOpts* opts, float* grad_x, float* grad_logp0, float* grad_params, void* workspace,
+                  size_t workspace_bytes, CnfStats* stats, void* stream) {
+    cnf::SolveArgs a;
+    return solve_bwd_impl("cnf_solve_bwd", false, net, params, z1, logp1, e, grad_z1, grad_logp1, rows, t0, t1, opts, grad_x,
+                          grad_logp0, grad_params, nullptr, workspace, workspace_bytes, stats, stream, a);
+}
+
+int cnf_solve_bwd_train(const CnfNetDesc* net, float* params, const float* z1, const float* logp1, const float* e,
+                        const float* grad_z1, const float* grad_logp1, int64_t rows, float t0, float t1,
+                        const CnfSolverOpts* opts, float* grad_x, float* grad_logp0, float* grad_params, float* loss_out,
+                        float* exp_avg, float* exp_avg_sq, int32_t* adam_state, const CnfAdamOpts* adam, void* workspace,
+                        size_t workspace_bytes, CnfStats* stats, void* stream) {
+    const char* who = "cnf_solve_bwd_train";
+    if (!exp_avg || !exp_avg_sq || !adam_state || !adam) return fail("%s: NULL pointer (optimizer state)", who);
+    if (!(adam->lr >= 0.) || !(adam->beta1 >= 0. && adam->beta1 < 1.) || !(adam->beta2 >= 0. && adam->beta2 < 1.) ||
+        !(adam->eps >= 0.) || !(adam->weight_decay >= 0.))
+        return fail("%s: invalid hyper-parameters (lr %g, betas %g %g, eps %g, weight_decay %g)", who, adam->lr, adam->beta1,
+                    adam->beta2, adam->eps, adam->weight_decay);
+    cnf::SolveArgs a;
+    if (solve_bwd_impl(who, true, net, params, z1, logp1, e, grad_z1, grad_logp1, rows, t0, t1, opts, grad_x, grad_logp0,
+                       grad_params, loss_out, workspace, workspace_bytes, stats, stream, a))
+        return 1;
+    const cnf::ParamLayout L = cnf::make_layout(net->dim, net->hidden);
+    const int tiles = (int)((rows + cnf::kRows - 1) / cnf::kRows);
+    hipError_t err = cnf::launch_adam_slabs(a.slab, tiles, L.total, a.spread ? L.w(2) : 0, grad_params, params, exp_avg,
+                                            exp_avg_sq, adam_state, *adam, (hipStream_t)stream);
+    if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
     return 0;
 }
 

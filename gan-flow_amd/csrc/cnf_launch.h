@@ -28,6 +28,10 @@ struct SolveArgs {
     float* grad_params;
     float* slab;          // per-workgroup parameter-gradient partials [nwg][P]
     int spread;           // adjoint, cnf_split.hip: two workgroups per tile, each keeping half of the d/dtheta sums
+    float* loss_out;      // adjoint, cnf_solve_bwd_train: non-null = the cotangents are those of the flow's NLL
+                          // (grad_z1 = z1 / rows, grad_logp1 = 1 / rows; grad_z1 / grad_logp1 are not read) and the
+                          // loss goes here
+    int keep_slabs;       // adjoint: leave the per-workgroup gradient slabs for launch_adam_slabs (no reduction kernel)
 };
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,

@@ -66,5 +66,8 @@ __device__ inline void stage_wimgT(float* img, const float* __restrict__ p, int 
 
 // sum of the workgroups' gradient slabs in a fixed order (kernel in cnf_split.hip)
 hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s, int split_at = 0);
+// slab sum (as launch_reduce_slab) + Adam update of the P parameters in one kernel; grad_out may be null
+hipError_t launch_adam_slabs(const float* slab, int ntiles, int P, int split_at, float* grad_out, float* p, float* m, float* v,
+                             int* state, const CnfAdamOpts& o, hipStream_t s);
 
 }  // namespace cnf

@@ -13,6 +13,7 @@
 // Used when rows <= 16 * 256 (every workgroup resident for the grid-wide reductions); larger batch-global solves
 // fall back to the one-wave-per-tile kernels.
 #include "cnf_split.h"
+#include "cnf_adam.h"
 
 namespace cnf {
 
@@ -864,15 +865,22 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     GridSync gs{a.gran, (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * D;
 
+    // a.loss_out: the cotangents are those of loss = -mean(sum_d log N(z1_d) - logp1) (nll_loss_kernel's arithmetic,
+    // cnf_train.hip); the loss itself rides on the second grid reduction, whose third slot is free
+    const bool nll = a.loss_out != nullptr;
+    const float inv_rows = 1.0f / (float)a.rows;
     float y0[C], y1[C], yi[C], ee[D];
+    float nll_row = 0.f;
 #pragma unroll
     for (int m = 0; m < D; ++m) {
         y0[m] = a.x[rr * D + m];
         ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
-        y0[D + 1 + m] = valid ? a.grad_z1[rr * D + m] : 0.f;
+        y0[D + 1 + m] = valid ? (nll ? y0[m] * inv_rows : a.grad_z1[rr * D + m]) : 0.f;
+        nll_row += -0.91893853320467274178f - y0[m] * y0[m] * 0.5f;
     }
     y0[D] = a.logp0[rr];
-    const float al = valid ? a.grad_logp1[rr] : 0.f;
+    nll_row -= y0[D];
+    const float al = valid ? (nll ? inv_rows : a.grad_logp1[rr]) : 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) yi[c] = y0[c];
 
@@ -965,7 +973,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                 const float u = (k[c] - ws.kst[0][c][j]) / sc[c];
                 if (counted) S[c < D ? 0 : 1] += (double)u * u;
             }
+            if (nll && counted) S[2] = (double)nll_row;
             if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * inv_rows);
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
             float h1;
             if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
@@ -1133,6 +1143,49 @@ hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hip
     return hipGetLastError();
 }
 
+// reduce_slab_split_kernel with the Adam update of the 64 parameters as its epilogue (cnf_solve_bwd_train): the sum is
+// formed exactly as above, so parameters and moments get the bits the two separate kernels would give them.
+__global__ __launch_bounds__(256) void adam_slab_kernel(const float* __restrict__ slab, int nwg, int P, int split_at,
+                                                        float* __restrict__ grad_out, float* __restrict__ p,
+                                                        float* __restrict__ m, float* __restrict__ v, int* __restrict__ state,
+                                                        CnfAdamOpts o) {
+    __shared__ float part[4][64];
+    __shared__ float corr[2];
+    AdamCoef c;
+    const int step = adam_begin(state, o, corr, c);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (i < P) {
+        const size_t stride = split_at > 0 ? 2 * (size_t)P : (size_t)P;
+        const float* src = slab + i + (split_at > 0 && i < split_at ? (size_t)P : 0);
+        int g = wv;
+        for (; g + 28 < nwg; g += 32) {
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = src[(size_t)(g + 4 * k) * stride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += x[k];
+        }
+        for (; g < nwg; g += 4) acc += src[(size_t)g * stride];
+    }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && i < P) {
+        const float g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (grad_out) grad_out[i] = g;
+        adam_update(c, g, p, m, v, i);
+    }
+    adam_end(state, step);
+}
+
+hipError_t launch_adam_slabs(const float* slab, int ntiles, int P, int split_at, float* grad_out, float* p, float* m, float* v,
+                             int* state, const CnfAdamOpts& o, hipStream_t s) {
+    hipLaunchKernelGGL(adam_slab_kernel, dim3((P + 63) / 64), dim3(256), 0, s, slab, ntiles, P, split_at, grad_out, p, m, v,
+                       state, o);
+    return hipGetLastError();
+}
+
 template <int D, bool HUTCH>
 static hipError_t split_fwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
@@ -1162,6 +1215,7 @@ static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
     dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
+    if (a.keep_slabs) return hipSuccess;
     const ParamLayout L = make_layout(D, kH);
     const int P = L.total;
     hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((P + 63) / 64), dim3(256), 0, s, a.slab, grid, P, a.grad_params,

@@ -746,20 +746,25 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     GridSync gs{a.gran, (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * kD;
 
+    // a.loss_out: NLL cotangents and the loss on the second grid reduction (see dopri5_bwd_split_kernel, cnf_split.hip)
+    const bool nll = a.loss_out != nullptr;
+    const float inv_rows = 1.0f / (float)a.rows;
+    float nll_part = 0.f;   // this lane's four components of sum_d log N(z1_d)
     float y0[kCA], y1[kCA], yi[kCA];
     const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.e + rr * kD + 4 * q);
     {
         const f32x4 x4 = *reinterpret_cast<const f32x4*>(a.x + rr * kD + 4 * q);
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.grad_z1 + rr * kD + 4 * q);
+        const f32x4 g4 = nll ? x4 * inv_rows : *reinterpret_cast<const f32x4*>(a.grad_z1 + rr * kD + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             y0[r] = x4[r];
             y0[5 + r] = valid ? g4[r] : 0.f;
             sb.tZ[1][(4 * q + r) * kRows + pos] = e4[r];
+            nll_part += -0.91893853320467274178f - x4[r] * x4[r] * 0.5f;
         }
     }
     y0[4] = a.logp0[rr];
-    const float al = valid ? a.grad_logp1[rr] : 0.f;
+    const float al = valid ? (nll ? inv_rows : a.grad_logp1[rr]) : 0.f;
 #pragma unroll
     for (int c = 0; c < kCA; ++c) yi[c] = y0[c];
     __syncthreads();
@@ -848,7 +853,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
                 const float u = (k[c] - sb.kst[0][c][lane]) / sc[c];
                 if (c < 4 ? cz : cl) S[c < 4 ? 0 : 1] += (double)u * u;
             }
+            if (nll) S[2] = (cz ? (double)nll_part : 0.0) - (cl ? (double)y0[4] : 0.0);
             if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * inv_rows);
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
             float h1;
             if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
@@ -991,6 +998,7 @@ hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s) {
     dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
+    if (a.keep_slabs) return hipSuccess;
     const ParamLayout L = make_layout(kD, kH);
     return launch_reduce_slab(a.slab, grid, L.total, a.grad_params, s, a.spread ? L.w(2) : 0);
 }

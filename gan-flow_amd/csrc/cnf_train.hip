@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/cnf_hip.h"
+#include "cnf_adam.h"
 
 namespace cnf {
 
@@ -38,46 +39,19 @@ __global__ __launch_bounds__(kLossThreads) void nll_loss_kernel(const float* __r
     if (threadIdx.x == 0) *loss_out = -(part[0] * inv);
 }
 
-// torch.optim.Adam (amsgrad=False, maximize=False; weight decay added to the gradient):
-//   g += wd * p;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;
-//   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),     t = step + 1.
-// `state` = {step, ticket}: every workgroup reads step, the last one to finish (ticket) stores step + 1.
+// torch.optim.Adam on a flat vector (arithmetic: cnf_adam.h).  `state` = {step, ticket}: every workgroup reads step, the
+// last one to finish stores step + 1.
 constexpr int kAdamThreads = 256;
 
 __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v,
                                                             int* __restrict__ state, long n, CnfAdamOpts o) {
     __shared__ float corr[2];
-    const float b2 = (float)o.beta2, w1 = (float)(1.0 - o.beta1), w2 = (float)(1.0 - o.beta2);
-    const float wd = (float)o.weight_decay, eps = (float)o.eps;
-    const int step = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 0) {
-        const double t = (double)(step + 1);
-        const double bc1 = 1.0 - pow(o.beta1, t), bc2 = 1.0 - pow(o.beta2, t);
-        corr[0] = (float)(o.lr / bc1);
-        corr[1] = (float)sqrt(bc2);
-    }
-    __syncthreads();
-    const float step_size = corr[0], bc2_sqrt = corr[1];
+    AdamCoef c;
+    const int step = adam_begin(state, o, corr, c);
     const long i = (long)blockIdx.x * kAdamThreads + threadIdx.x;
-    if (i < n) {
-        const float pi = p[i];
-        const float gi = fmaf(wd, pi, g[i]);
-        const float mi = fmaf(gi - m[i], w1, m[i]);
-        const float vi = fmaf(b2, v[i], w2 * gi * gi);
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - step_size * (mi / denom);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(&state[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == (int)gridDim.x - 1) {
-            __hip_atomic_store(&state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&state[0], step + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (i < n) adam_update(c, g[i], p, m, v, i);
+    adam_end(state, step);
 }
 
 // Diagnostics: overwrite the whole LDS of every CU with a bit pattern (cnf_debug_fill_lds).  LDS keeps what the last

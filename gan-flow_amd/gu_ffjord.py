@@ -132,7 +132,8 @@ class FusedTrainStep:
         forward solve(s) -> cnf_nll_loss (loss + its gradient) -> adjoint solve(s) -> cnf_adam_step
 
     i.e. 4 kernels (+ the slab reduction) per CNF block instead of the ~100 launches that autograd, the loss
-    expression and torch.optim.Adam add around the two solves.  The arithmetic is that of
+    expression and torch.optim.Adam add around the two solves; at hidden width 64 cnf_solve_bwd_train folds the loss
+    into the adjoint kernel and the Adam update into the slab reduction: 3 kernels per block (fuse_tail).  The arithmetic is that of
     `loss = compute_loss(model, x); loss.backward(); Adam(lr, betas, eps, weight_decay).step()`; the parameters
     are updated in place through ODEnet.flatten_parameters(), so `model` (state_dict, evaluation) always sees the
     trained weights.  As in the reference, `sqrt_end_time` receives no gradient (T enters the solve detached).
@@ -140,7 +141,9 @@ class FusedTrainStep:
     device until .check()."""
 
     def __init__(self, model, example_batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, graph=True,
-                 warmup_batches=(), spread=True):
+                 warmup_batches=(), spread=True, fuse_tail=True):
+        # fuse_tail: use cnf_solve_bwd_train (same arithmetic, fewer kernels) where it is built
+        self.fuse_tail = bool(fuse_tail)
         # spread: flag the adjoint solves CNF_FLAG_SPREAD (include/cnf_hip.h): two workgroups per 16-row tile when the
         # batch would leave half the compute units idle.  Same results; must be False for trials that share a GPU
         # (ConcurrentTrials), whose solves have to be resident side by side.
@@ -205,12 +208,24 @@ class FusedTrainStep:
                 opts.flags |= nat.FLAG_SPREAD
             z, lp, _ = nat.solve_fwd(net, self.flats[i], z, lp, t0, t1, opts, e, stats=self.stats[i, 0], workspace=self.workspace)
             tape.append((net, t0, t1, opts, e, z, lp))
-        loss, gz, gl = nat.nll_loss(z, lp)
-        for i in range(len(self.blocks) - 1, -1, -1):
+        # the tail: cnf_solve_bwd_train (adjoint + slab sum + Adam in two kernels; for the last block also the loss and its
+        # cotangents) where it is built -- hidden width 64, <= 4096 rows -- else cnf_nll_loss, cnf_solve_bwd, cnf_adam_step
+        last = len(self.blocks) - 1
+        fused = [self.fuse_tail and tape[i][0].hidden == 64 and z.shape[0] <= 4096 for i in range(last + 1)]
+        loss = gz = gl = None
+        if not fused[last]:
+            loss, gz, gl = nat.nll_loss(z, lp)
+        for i in range(last, -1, -1):
             net, t0, t1, opts, e, z1, lp1 = tape[i]
-            gz, gl, gp, _ = nat.solve_bwd(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, e, stats=self.stats[i, 1],
-                                          workspace=self.workspace)
-            nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], **self.hyper)
+            if fused[i]:
+                gz, gl, _, l_, _ = nat.solve_bwd_train(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, self.exp_avg[i],
+                                                       self.exp_avg_sq[i], self.adam_state[i], e, stats=self.stats[i, 1],
+                                                       workspace=self.workspace, **self.hyper)
+                loss = l_ if l_ is not None else loss
+            else:
+                gz, gl, gp, _ = nat.solve_bwd(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, e, stats=self.stats[i, 1],
+                                              workspace=self.workspace)
+                nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], **self.hyper)
         return loss
 
     def __call__(self, x):

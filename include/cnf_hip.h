@@ -156,6 +156,23 @@ typedef struct CnfAdamOpts {
 int cnf_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, int32_t *state,
                   int64_t n, const CnfAdamOpts *opts, void *stream);
 
+/* The tail of a training iteration for one CNF block in two kernels: the adjoint solve of cnf_solve_bwd, then the sum
+ * of its per-workgroup gradient partials with the Adam update of cnf_adam_step as that kernel's epilogue (what the
+ * reference's driver does with `loss.backward(); optimizer.step()`).  Same arguments as those
+ * two calls, and the same bits in every output.  Two things differ:
+ *   - grad_z1 == NULL (then grad_logp1 must be NULL as well) selects the cotangents of the flow's NLL,
+ *     grad_z1 = z1 / rows and grad_logp1 = 1 / rows, formed inside the adjoint kernel, and stores that loss
+ *     (cnf_nll_loss's value up to summation order) to loss_out: for the LAST block of a flow this replaces cnf_nll_loss;
+ *   - grad_params may be NULL (the summed gradient is then not stored anywhere).
+ * `params` is updated in place AFTER the solve has read it.  Hidden width 64, at most 4096 rows; otherwise the call
+ * fails and the three separate entry points are to be used.                                                   */
+int cnf_solve_bwd_train(const CnfNetDesc *net, float *params, const float *z1, const float *logp1,
+                        const float *e, const float *grad_z1, const float *grad_logp1, int64_t rows,
+                        float t0, float t1, const CnfSolverOpts *opts, float *grad_x, float *grad_logp0,
+                        float *grad_params, float *loss_out, float *exp_avg, float *exp_avg_sq,
+                        int32_t *adam_state, const CnfAdamOpts *adam, void *workspace, size_t workspace_bytes,
+                        CnfStats *stats, void *stream);
+
 /* Diagnostics (no counterpart in the reference): fill the LDS of every compute unit with `pattern`.  LDS keeps the
  * previous kernel's content, so the tests poison it (NaN bit patterns) before a solve to prove that no result
  * depends on it.  scratch_word: one uint32 of device memory (never written in practice).                    */

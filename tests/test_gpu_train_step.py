@@ -113,6 +113,33 @@ def test_fused_train_step_matches_autograd_loop(graph, blocks):
     assert model.chain[0].num_evals() > 0
 
 
+@pytest.mark.parametrize("dim,blocks,rows,div", [(2, 1, 2048, "brute_force"), (2, 2, 1000, "brute_force"), (1, 1, 77, "brute_force"),
+                                                 (16, 1, 2048, "approximate"), (2, 1, 300, "approximate")])
+def test_solve_bwd_train_equals_separate_calls(dim, blocks, rows, div):
+    """cnf_solve_bwd_train (loss + cotangents inside the adjoint kernel, Adam as the epilogue of the slab sum) against
+    cnf_nll_loss / cnf_solve_bwd / cnf_adam_step: parameters and Adam moments identical bit for bit after every step,
+    losses equal to the rounding of a different summation order."""
+    from gan_flow_amd import gu_ffjord
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(rows, dim, generator=g) * 1.5 + 0.3).to(DEV) for _ in range(4)]
+    runs = []
+    for fuse in (False, True):
+        torch.manual_seed(6)
+        model = gu_ffjord.build_model(dim, num_blocks=blocks, divergence_fn=div, rademacher=True).to(DEV).train()
+        step = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=False, fuse_tail=fuse)
+        if div == "approximate":     # same Rademacher probes for both runs
+            torch.manual_seed(77)
+        losses = [step(x).item() for x in batches]
+        nfe = step.check()
+        runs.append((losses, nfe, [f.clone() for f in step.flats], [m.clone() for m in step.exp_avg],
+                     [v.clone() for v in step.exp_avg_sq], step.step_count))
+    (l0, n0, p0, m0, v0, c0), (l1, n1, p1, m1, v1, c1) = runs
+    assert n0 == n1 and c0 == c1 == len(batches)
+    assert all(abs(a - b) <= 2e-6 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
+    for a, b in zip(p0 + m0 + v0, p1 + m1 + v1):
+        assert torch.equal(a, b)
+
+
 def test_fused_train_step_two_blocks_hutchinson():
     """Stacked blocks + Hutchinson divergence: the loss gradient is chained through the blocks in reverse."""
     from gan_flow_amd import gu_ffjord
