@@ -1109,6 +1109,30 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------
+// One wave's share of a parameter's column of slabs: g = wv, wv + 4, ... added in that order.  The slabs were written by
+// other compute units (other XCDs: every load is a trip past the local L2), so 32 loads are in flight before the first
+// addition -- a 128-tile batch is ONE round trip per thread instead of four.
+__device__ __forceinline__ float slab_column_sum(const float* __restrict__ src, size_t stride, int wv, int nwg) {
+    float acc = 0.f;
+    int g = wv;
+    for (; g + 124 < nwg; g += 128) {
+        float x[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) x[k] = src[(size_t)(g + 4 * k) * stride];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc += x[k];
+    }
+    for (; g + 28 < nwg; g += 32) {
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = src[(size_t)(g + 4 * k) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += x[k];
+    }
+    for (; g < nwg; g += 4) acc += src[(size_t)g * stride];
+    return acc;
+}
+
 // Sum of the workgroups' slabs in a FIXED order (deterministic gradients).  64 parameters per block; the four waves
 // of a block take the slabs g = wave, wave + 4, ... (eight independent loads in flight per thread), LDS combines the
 // four partial sums as (w0 + w1) + (w2 + w3).
@@ -1123,15 +1147,7 @@ __global__ __launch_bounds__(256) void reduce_slab_split_kernel(const float* __r
     if (p < P) {
         const size_t stride = split_at > 0 ? 2 * (size_t)P : (size_t)P;
         const float* src = slab + p + (split_at > 0 && p < split_at ? (size_t)P : 0);
-        int g = wv;
-        for (; g + 28 < nwg; g += 32) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(g + 4 * k) * stride];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc += v[k];
-        }
-        for (; g < nwg; g += 4) acc += src[(size_t)g * stride];
+        acc = slab_column_sum(src, stride, wv, nwg);
     }
     part[wv][lane] = acc;
     __syncthreads();
@@ -1151,30 +1167,31 @@ __global__ __launch_bounds__(256) void adam_slab_kernel(const float* __restrict_
                                                         CnfAdamOpts o) {
     __shared__ float part[4][64];
     __shared__ float corr[2];
-    AdamCoef c;
-    const int step = adam_begin(state, o, corr, c);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
+    // every independent load is issued before anything waits: the step count, the parameter and its moments (wave 0),
+    // the slabs (all waves); the bias corrections (two double-precision pow) are wave 3's job while the others add
+    const int step = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float pi = 0.f, mi = 0.f, vi = 0.f;
+    if (wv == 0 && i < P) {
+        pi = p[i];
+        mi = m[i];
+        vi = v[i];
+    }
     float acc = 0.f;
     if (i < P) {
         const size_t stride = split_at > 0 ? 2 * (size_t)P : (size_t)P;
         const float* src = slab + i + (split_at > 0 && i < split_at ? (size_t)P : 0);
-        int g = wv;
-        for (; g + 28 < nwg; g += 32) {
-            float x[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = src[(size_t)(g + 4 * k) * stride];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc += x[k];
-        }
-        for (; g < nwg; g += 4) acc += src[(size_t)g * stride];
+        acc = slab_column_sum(src, stride, wv, nwg);
     }
     part[wv][lane] = acc;
+    if (threadIdx.x == 255) adam_corrections(step, o, corr);
     __syncthreads();
     if (wv == 0 && i < P) {
+        const AdamCoef c = adam_coef(o, corr);
         const float g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
         if (grad_out) grad_out[i] = g;
-        adam_update(c, g, p, m, v, i);
+        adam_apply(c, g, pi, mi, vi, p, m, v, i);
     }
     adam_end(state, step);
 }
