@@ -432,7 +432,10 @@ __device__ inline void grid_cleanup(GridSync& gs, RedLds& red, int tid) {
     unsigned* ticket = reinterpret_cast<unsigned*>(gs.gran + kGranWords);
     __syncthreads();
     if (tid == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // relaxed: the barrier above follows this workgroup's last poll (its loads have returned), and the granules are
+        // only ever written with agent-scope atomic stores that every poller has already seen; an agent-scope release
+        // here would write the whole L2 back at the end of every solve
+        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         red.last = prev == (unsigned)gs.nwg - 1u;
     }
     __syncthreads();

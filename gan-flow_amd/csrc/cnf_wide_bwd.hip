@@ -444,9 +444,10 @@ template <int D>
 __device__ inline void wide_commit(float* __restrict__ region, const int (&sl)[7], const float (&wts)[7], bool first, int tid,
                                    int part = 0) {
     constexpr int SF = kWideSlotF<D>;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // the slots are written and folded by waves of this one workgroup (one compute unit, one vector L1): workgroup scope
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     f32x4* tot = reinterpret_cast<f32x4*>(region + (size_t)kWideTotal * SF);
     constexpr int U = 4;
     // the slot as two ranges of 16-byte words: [matrix sums | small-parameter sums]; a spread workgroup (part 1 / 2) folds
