@@ -102,6 +102,8 @@ def main():
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     dev = torch.device("cuda", local if backend == "nccl" else local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    # ranks that share a GPU (the gloo rehearsal only) must not launch adjoints that occupy every compute unit
+    spread = not (backend != "nccl" and world > torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -132,7 +134,7 @@ def main():
     graphed = None
     if args.mode == "fused":
         # library kernels only: forward solve, loss + gradient, adjoint solve, Adam; warm-up iterations are real steps
-        graphed = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=True,
+        graphed = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=True, spread=spread,
                                            warmup_batches=batches[:max(1, args.warmup)])
         barrier()
         t0 = time.perf_counter()
@@ -184,7 +186,7 @@ def main():
     }
 
     extras = set(e for e in args.extras.split(",") if e)
-    ctx = dict(args=args, world=world, rank=rank, dev=dev, batches=batches, model=model, barrier=barrier,
+    ctx = dict(args=args, world=world, rank=rank, dev=dev, batches=batches, model=model, barrier=barrier, spread=spread,
                max_over_ranks=max_over_ranks)
     if "roofline" in extras and rank == 0:
         out["roofline"] = measure_roofline(ctx)
@@ -219,7 +221,7 @@ def measure_roofline(ctx):
     fn = blk.odefunc.odefunc
     net = fn.net_desc()
     params = fn.diffeq.flat_parameters().detach()
-    opts = _native.make_opts("dopri5", blk.rtol, blk.atol, flags=_native.FLAG_SPREAD)   # as the timed training step launches it
+    opts = _native.make_opts("dopri5", blk.rtol, blk.atol, flags=_native.FLAG_SPREAD if ctx["spread"] else 0)   # as the timed step launches it
     T = float(blk.sqrt_end_time.detach() ** 2)
     x = batches[-1]
     z1, l1, _ = _native.solve_fwd(net, params, x, None, 0.0, T, opts)
@@ -257,7 +259,7 @@ def measure_late(ctx):
     args, world, rank, dev, batches = ctx["args"], ctx["world"], ctx["rank"], ctx["dev"], ctx["batches"]
     torch.manual_seed(1 + rank)
     late = embed_trained_multimodal(gu_ffjord.build_model(2)).to(dev).train()
-    step = gu_ffjord.FusedTrainStep(late, batches[0], lr=1e-5, weight_decay=1e-5, graph=False)
+    step = gu_ffjord.FusedTrainStep(late, batches[0], lr=1e-5, weight_decay=1e-5, graph=False, spread=ctx["spread"])
     step(batches[0])
     ctx["barrier"]()
     t0 = time.perf_counter()
@@ -283,7 +285,7 @@ def measure_d16(ctx):
     torch.manual_seed(1 + rank)
     model = gu_ffjord.build_model(16, divergence_fn="approximate").to(dev).train()
     xs = [data.get_sample(args.batch) for _ in range(args.warmup + args.steps)]
-    step = gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True,
+    step = gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True, spread=ctx["spread"],
                                     warmup_batches=xs[:max(1, args.warmup)])
     ctx["barrier"]()
     t0 = time.perf_counter()
@@ -371,7 +373,7 @@ def measure_wide(ctx):
     data = make_gu(8, device="cpu", seed=1 + rank, extend_dim=True)
     n_it = max(3, args.steps // 3)
     xs = [data.get_sample(args.batch).to(dev) for _ in range(2 + n_it)]
-    step = gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True, warmup_batches=xs[:2])
+    step = gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True, warmup_batches=xs[:2], spread=ctx["spread"])
     ctx["barrier"]()
     t0 = time.perf_counter()
     for x in xs[2:]:
