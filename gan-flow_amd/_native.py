@@ -32,6 +32,7 @@ class CnfAdamOpts(ctypes.Structure):
 
 SOLVER_IDS = {"dopri5": 0, "rk4": 1, "euler": 2, "midpoint": 3}
 DIV_EXACT, DIV_HUTCHINSON = 0, 1
+DIV_RESIDUAL = 256   # CNF_DIV_RESIDUAL, OR-ed into CnfNetDesc.divergence
 STATUS_MESSAGES = {
     1: "underflow in dt {last_dt}",
     2: "non-finite values in state `y`",
@@ -141,8 +142,10 @@ def _own_workspace(lib, net, rows, ws):
     return ws
 
 
-def net_desc(dim, hidden, n_hidden, hutchinson):
-    return CnfNetDesc(int(dim), int(hidden), int(n_hidden), DIV_HUTCHINSON if hutchinson else DIV_EXACT)
+def net_desc(dim, hidden, n_hidden, hutchinson, residual=False):
+    """residual: ODEfunc(residual=True), dynamics f(t, y) - y (CNF_DIV_RESIDUAL)."""
+    return CnfNetDesc(int(dim), int(hidden), int(n_hidden),
+                      (DIV_HUTCHINSON if hutchinson else DIV_EXACT) | (DIV_RESIDUAL if residual else 0))
 
 
 def param_count(net):

@@ -24,7 +24,7 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state,
 hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s);
 // hidden width 256, forward path (cnf_wide.hip)
 hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
-                             float* f_out, float* nd_out, hipStream_t s);
+                             float* f_out, float* nd_out, hipStream_t s, float res);
 hipError_t launch_wide_solve(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
 // hidden width 256, adjoint (cnf_wide_bwd.hip); ws_floats = workspace past the granules
 size_t wide_bwd_workspace_floats(int D, long rows);
@@ -67,11 +67,13 @@ constexpr size_t kGranBytes = 2 * (size_t)cnf::kMaxWG * 4 * sizeof(unsigned long
 constexpr int kWideH = 256;   // cnf_wide.hip
 
 bool is_wide(const CnfNetDesc* n) { return n->hidden == kWideH; }
+bool is_residual(const CnfNetDesc* n) { return (n->divergence & CNF_DIV_RESIDUAL) != 0; }
 
 bool supported(const CnfNetDesc* n) {
     if (!n || (n->hidden != cnf::kH && n->hidden != kWideH) || n->n_hidden != 3) return false;
-    const bool hutch = n->divergence == CNF_DIV_HUTCHINSON;
-    if (n->divergence != CNF_DIV_EXACT && !hutch) return false;
+    const int kind = n->divergence & ~CNF_DIV_RESIDUAL;
+    const bool hutch = kind == CNF_DIV_HUTCHINSON;
+    if (kind != CNF_DIV_EXACT && !hutch) return false;
     if (is_wide(n)) return (n->dim == 1 && !hutch) || n->dim == 2;
     return (n->dim == 1 && !hutch) || n->dim == 2 || (n->dim == 16 && hutch);
 }
@@ -152,15 +154,17 @@ int cnf_eval_field(const CnfNetDesc* net, const float* params, float t, const fl
     if (check_net(net)) return 1;
     if (!params || !z || !f_out || !neg_div_out) return fail("cnf_eval_field: NULL pointer");
     if (rows <= 0) return fail("cnf_eval_field: rows must be positive (got %ld)", (long)rows);
-    const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
+    const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
     if (hutch && !e) return fail("cnf_eval_field: Hutchinson divergence needs the probe e");
     if (is_wide(net)) {
         if (((uintptr_t)params & 15) != 0) return fail("cnf_eval_field: params must be 16-byte aligned for hidden width 256");
-        hipError_t werr = cnf::launch_wide_field(net->dim, hutch, params, t, z, e, rows, f_out, neg_div_out, (hipStream_t)stream);
+        hipError_t werr = cnf::launch_wide_field(net->dim, hutch, params, t, z, e, rows, f_out, neg_div_out, (hipStream_t)stream,
+                                                 is_residual(net) ? 1.f : 0.f);
         if (werr != hipSuccess) return fail("cnf_eval_field: launch failed: %s", hipGetErrorString(werr));
         return 0;
     }
-    hipError_t err = cnf::launch_field(net->dim, hutch, params, t, z, e, rows, f_out, neg_div_out, (hipStream_t)stream);
+    hipError_t err = cnf::launch_field(net->dim, hutch, params, t, z, e, rows, f_out, neg_div_out, (hipStream_t)stream,
+                                       is_residual(net) ? 1.f : 0.f);
     if (err != hipSuccess) return fail("cnf_eval_field: launch failed: %s", hipGetErrorString(err));
     return 0;
 }
@@ -187,6 +191,7 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
     a.slab = (float*)((char*)workspace + kGranBytes);
     a.stats = stats;
     a.n_grid = 1;
+    a.residual = is_residual(net) ? 1 : 0;
     a.step_size = 0.f;
     global = true;
     if (opts->solver == CNF_SOLVER_DOPRI5) {
@@ -235,7 +240,7 @@ int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, co
     bool global;
     if (fill_common("cnf_solve_fwd", net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
     if (!x || !z_out || !logp_out) return fail("cnf_solve_fwd: NULL pointer");
-    const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
+    const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
     if (hutch && !e) return fail("cnf_solve_fwd: Hutchinson divergence needs the probe e");
     a.x = x;
     a.logp0 = logp0;
@@ -272,12 +277,13 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
     if (n_wg(rows) > cnf::kMaxWG) return fail("cnf_eval_aug: at most %d rows", cnf::kMaxWG * cnf::kRowsPerWG);
     const size_t need = cnf_workspace_bytes(net, rows);
     if (workspace_bytes < need) return fail("cnf_eval_aug: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
-    const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
+    const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
     if (hutch && !e) return fail("cnf_eval_aug: Hutchinson divergence needs the probe e");
     if (check_adjoint_rows("cnf_eval_aug", net, rows)) return 1;
     cnf::SolveArgs a{};
     a.params = params;
     a.rows = rows;
+    a.residual = is_residual(net) ? 1 : 0;
     a.e = e;
     a.gran = (unsigned long long*)workspace;
     a.slab = (float*)((char*)workspace + kGranBytes);
@@ -325,7 +331,7 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
                     "cnf_solve_bwd and cnf_adam_step", who, cnf::kRows * cnf::kMaxWG, net->hidden, (long)rows);
     if (opts->solver != CNF_SOLVER_DOPRI5) return fail("%s: the adjoint pass is built for dopri5 only", who);
     if (!global) return fail("%s: the adjoint pass needs batch-global step control (tile_rows = 0)", who);
-    const bool hutch = net->divergence == CNF_DIV_HUTCHINSON;
+    const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
     if (hutch && !e) return fail("%s: Hutchinson divergence needs the probe e", who);
     if (check_adjoint_rows(who, net, rows)) return 1;
     a.loss_out = nll ? loss_out : nullptr;

@@ -492,6 +492,7 @@ __global__ __launch_bounds__(kThreads) void aug_kernel(SolveArgs a, float t, con
                                                        const float* __restrict__ a_z, const float* __restrict__ a_l,
                                                        float* __restrict__ f_out, float* __restrict__ nd_out,
                                                        float* __restrict__ vz_out) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLds<D> net;
     __shared__ BwdNetLds netT;
     __shared__ BwdWaveLds<D> wl[kNW];
@@ -515,6 +516,12 @@ __global__ __launch_bounds__(kThreads) void aug_kernel(SolveArgs a, float t, con
     BigAcc acc;
     acc.zero();
     aug_eval<D, HUTCH>(net, netT, wl[w], lane, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc, netT, w);
+    #pragma unroll
+    for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+        f[m] = fmaf(-res, zz[m], f[m]);
+        vz[m] = fmaf(res, az[m], vz[m]);
+    }
+    div -= res * (float)D;
     if (lane < 16 && valid) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -529,6 +536,7 @@ __global__ __launch_bounds__(kThreads) void aug_kernel(SolveArgs a, float t, con
 // ---- the adjoint solve -------------------------------------------------------------------------------------
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLds<D> net;
     __shared__ BwdNetLds netT;
     __shared__ BwdWaveLds<D> wl[kNW];
@@ -592,6 +600,12 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
         // initial-step evaluations only need (f, div); the sweep still runs (one code path), its outputs are unused
         aug_eval<D, HUTCH>(net, netT, ws, lane, sgn * ti, zz, ee, az, al, phase == PH_STAGE ? sgn * ws.wq[stage] : 0.f,
                            with_theta, f, div, vz, acc, netT, w);
+        #pragma unroll
+        for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+            f[m] = fmaf(-res, zz[m], f[m]);
+            vz[m] = fmaf(res, az[m], vz[m]);
+        }
+        div -= res * (float)D;
         ++nrun;
 #pragma unroll
         for (int m = 0; m < D; ++m) {

@@ -15,7 +15,7 @@ template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict__ params, float t,
                                                          const float* __restrict__ z, const float* __restrict__ e,
                                                          long rows, float* __restrict__ f_out,
-                                                         float* __restrict__ neg_div_out) {
+                                                         float* __restrict__ neg_div_out, float res) {
     __shared__ NetLds<D> net;
     __shared__ WaveLds<D> wl[kNW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
@@ -32,6 +32,9 @@ __global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict
         ee[m] = HUTCH ? e[rr * D + m] : 0.f;
     }
     field_fwd<D, HUTCH>(net, wl[w], lane, t, zz, ee, f, div);
+    #pragma unroll
+    for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
+    div -= res * (float)D;
     if (lane < 16 && row < rows) {
 #pragma unroll
         for (int m = 0; m < D; ++m) f_out[row * D + m] = f[m];
@@ -57,6 +60,7 @@ constexpr int kEvalWaves = CNF_EVAL_WAVES, kEvalNW = CNF_EVAL_NW;
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D > 2 ? 1 : kEvalWaves, D > 2 ? 8 : kEvalWaves)))
 void rk4_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLds<D> net;
     __shared__ WaveLds<D> wl[kNW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
@@ -92,6 +96,9 @@ void rk4_kernel(SolveArgs a) {
 #pragma unroll
             for (int m = 0; m < D; ++m) zz[m] = yi[m];
             field_fwd<D, HUTCH>(net, wl[w], lane, sgn * ti, zz, ee, f, div);
+            #pragma unroll
+            for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
+            div -= res * (float)D;
 #pragma unroll
             for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
             k[D] = -sgn * div;
@@ -151,6 +158,7 @@ template <int D, bool HUTCH, bool GLOBAL, int NW>
 __global__ __launch_bounds__(NW * 64)
     __attribute__((amdgpu_waves_per_eu(GLOBAL || D > 2 ? 1 : kEvalWaves, GLOBAL || D > 2 ? 8 : kEvalWaves)))
     void dopri5_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLds<D> net;
     __shared__ WaveLds<D> wl[NW];
     __shared__ RedLds red;
@@ -205,6 +213,9 @@ __global__ __launch_bounds__(NW * 64)
 #pragma unroll
         for (int m = 0; m < D; ++m) zz[m] = yi[m];
         field_fwd<D, HUTCH>(net, ws, lane, sgn * ti, zz, ee, f, div);
+        #pragma unroll
+        for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
+        div -= res * (float)D;
         ++nfe;
 #pragma unroll
         for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
@@ -373,18 +384,18 @@ __global__ __launch_bounds__(NW * 64)
 // ------------------------------------------------------------------------------------------------
 template <int D, bool HUTCH>
 static hipError_t launch_field_t(const float* params, float t, const float* z, const float* e, long rows,
-                                 float* f_out, float* nd_out, hipStream_t s) {
+                                 float* f_out, float* nd_out, hipStream_t s, float res) {
     const int grid = (int)((rows + kRowsPerWG - 1) / kRowsPerWG);
-    hipLaunchKernelGGL((field_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, params, t, z, e, rows, f_out, nd_out);
+    hipLaunchKernelGGL((field_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, params, t, z, e, rows, f_out, nd_out, res);
     return hipGetLastError();
 }
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
-                        float* f_out, float* nd_out, hipStream_t s) {
-    if (D == 1 && !hutch) return launch_field_t<1, false>(params, t, z, e, rows, f_out, nd_out, s);
-    if (D == 2 && !hutch) return launch_field_t<2, false>(params, t, z, e, rows, f_out, nd_out, s);
-    if (D == 2 && hutch) return launch_field_t<2, true>(params, t, z, e, rows, f_out, nd_out, s);
-    if (D == 16 && hutch) return launch_field_t<16, true>(params, t, z, e, rows, f_out, nd_out, s);
+                        float* f_out, float* nd_out, hipStream_t s, float res) {
+    if (D == 1 && !hutch) return launch_field_t<1, false>(params, t, z, e, rows, f_out, nd_out, s, res);
+    if (D == 2 && !hutch) return launch_field_t<2, false>(params, t, z, e, rows, f_out, nd_out, s, res);
+    if (D == 2 && hutch) return launch_field_t<2, true>(params, t, z, e, rows, f_out, nd_out, s, res);
+    if (D == 16 && hutch) return launch_field_t<16, true>(params, t, z, e, rows, f_out, nd_out, s, res);
     return hipErrorInvalidValue;
 }
 

@@ -31,11 +31,12 @@ struct SolveArgs {
     float* loss_out;      // adjoint, cnf_solve_bwd_train: non-null = the cotangents are those of the flow's NLL
                           // (grad_z1 = z1 / rows, grad_logp1 = 1 / rows; grad_z1 / grad_logp1 are not read) and the
                           // loss goes here
+    int residual;         // CNF_DIV_RESIDUAL: the dynamics are f(z) - z (ODEfunc(residual=True))
     int keep_slabs;       // adjoint: leave the per-workgroup gradient slabs for launch_adam_slabs (no reduction kernel)
 };
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
-                        float* f_out, float* nd_out, hipStream_t s);
+                        float* f_out, float* nd_out, hipStream_t s, float res = 0.f);
 hipError_t launch_solve_fwd(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
 // d = 16, Hutchinson, rows <= 4096, x / e / z_out / params 16-byte aligned (cnf_split16.hip)
 hipError_t launch_split16_fwd(const SolveArgs& a, hipStream_t s);

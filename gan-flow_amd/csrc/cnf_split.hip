@@ -180,6 +180,7 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
 // ---- forward solve -----------------------------------------------------------------------------------------
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int C = D + 1;
     __shared__ NetLds<D> net;
     __shared__ SplitWaveLds<C> wl[kNW];
@@ -230,6 +231,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
         for (int m = 0; m < D; ++m) zz[m] = yi[m];
         pr.mark(0);
         field_fwd_split<D, HUTCH>(net, ws, xc, lane, w, sgn * ti, zz, ee, f, div, pr);
+        #pragma unroll
+        for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
+        div -= res * (float)D;
         ++nfe;
 #pragma unroll
         for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
@@ -798,6 +802,7 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
                                                              const float* __restrict__ a_z, const float* __restrict__ a_l,
                                                              float* __restrict__ f_out, float* __restrict__ nd_out,
                                                              float* __restrict__ vz_out) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int C = 2 * D + 1;
     __shared__ NetLds<D> net;
     __shared__ SplitBwdLds<D> sb;
@@ -822,6 +827,12 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     BigAccS acc;
     acc.zero();
     aug_eval_split<D, HUTCH>(net, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc, 0);
+    #pragma unroll
+    for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+        f[m] = fmaf(-res, zz[m], f[m]);
+        vz[m] = fmaf(res, az[m], vz[m]);
+    }
+    div -= res * (float)D;
     if (w == 0 && lane < 16 && valid) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -835,6 +846,7 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
 
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int C = 2 * D + 1;
     constexpr int CE = D + 1;
     __shared__ NetLds<D> net;
@@ -924,6 +936,12 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             acc.zero();
         }
         aug_eval_split<D, HUTCH>(net, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc, small, part);
+        #pragma unroll
+        for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+            f[m] = fmaf(-res, zz[m], f[m]);
+            vz[m] = fmaf(res, az[m], vz[m]);
+        }
+        div -= res * (float)D;
         if (FSAL && (to_first || to_last)) {
             if (to_first) gfirst = acc;
             else glast = acc;

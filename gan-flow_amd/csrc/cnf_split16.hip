@@ -129,6 +129,7 @@ __device__ __forceinline__ void field_fwd16(const NetLds<kD>& n, Wave16Lds& ws, 
 
 // ---- forward solve: the controller of dopri5_split_kernel on 5 components per lane --------------------------------
 __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLds<kD> net;
     __shared__ Wave16Lds wl[kNW];
     __shared__ Xchg16 xc;
@@ -182,6 +183,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) z4[r] = yi[r];
         field_fwd16(net, ws, xc, w1img, w4img, lane, w, sgn * ti, z4, e4, f4, div);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f4[r] = fmaf(-res, z4[r], f4[r]);   // residual dynamics f(z) - z (res = 0 or 1)
+        div -= res * (float)kD;
         ++nfe;
 #pragma unroll
         for (int r = 0; r < 4; ++r) k[r] = sgn * f4[r];
@@ -713,6 +717,7 @@ __device__ inline void commit16(Bwd16Lds& sb, const Acc16<HALF>& A, const Acc16<
 // evaluations per attempt).  Otherwise one workgroup per tile keeps all sums and re-evaluates the first stage (seven).
 template <bool SPREAD>
 __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ Net16Lds net;
     __shared__ Bwd16Lds sb;
     __shared__ Xchg16 xc;
@@ -808,6 +813,12 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
         aug_eval16(net, sb, xc, w1img, w4img, w1Timg, w4Timg, lane, w, sgn * ti, z4, e4, az4, al, sgn * wst, with_theta, f4, div,
                    vz4, acc.dw(0), acc.dw(1), acc.thin(0), acc.thin(1), part,
                    to_first ? i_first * kSm16 : (to_last ? i_last * kSm16 : 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+            f4[r] = fmaf(-res, z4[r], f4[r]);
+            vz4[r] = fmaf(res, az4[r], vz4[r]);
+        }
+        div -= res * (float)kD;
         if (to_first) swap16(acc, gfirst);
         if (to_last) swap16(acc, glast);
         ++nrun;

@@ -167,7 +167,8 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) void wide_field_kernel(const float* __restrict__ params,
                                                               float t, const float* __restrict__ z, const float* __restrict__ e,
-                                                              long rows, float* __restrict__ f_out, float* __restrict__ nd_out) {
+                                                              long rows, float* __restrict__ f_out, float* __restrict__ nd_out,
+                                                              float res) {
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     __shared__ WideNetLds<D> net;
     __shared__ WideWaveLds<D + 1> wl[kNW];
@@ -184,6 +185,9 @@ __global__ __launch_bounds__(kThreads) void wide_field_kernel(const float* __res
         ee[m] = HUTCH ? e[rr * D + m] : 0.f;
     }
     field_fwd_wide<D, HUTCH>(net, wl[w], xc, params, lane, w, t, zz, ee, f, div);
+    #pragma unroll
+    for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
+    div -= res * (float)D;
     if (w == 0 && lane < 16 && row < rows) {
 #pragma unroll
         for (int m = 0; m < D; ++m) f_out[row * D + m] = f[m];
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(kThreads) void wide_field_kernel(const float* __res
 // ---- fixed-grid RK4 (3/8 rule), as rk4_kernel in cnf_fwd.hip ---------------------------------------------------
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void wide_rk4_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = D + 1;
     __shared__ WideNetLds<D> net;
@@ -228,6 +233,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int m = 0; m < D; ++m) zz[m] = yi[m];
             field_fwd_wide<D, HUTCH>(net, wl[w], xc, a.params, lane, w, sgn * ti, zz, ee, f, div);
+            #pragma unroll
+            for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
+            div -= res * (float)D;
 #pragma unroll
             for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
             k[D] = -sgn * div;
@@ -282,6 +290,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int D, bool HUTCH, bool GLOBAL>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GLOBAL ? 1 : 2, GLOBAL ? 8 : 2)))
 void wide_dopri5_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = D + 1;
     __shared__ WideNetLds<D> net;
@@ -340,6 +349,9 @@ void wide_dopri5_kernel(SolveArgs a) {
 #pragma unroll
         for (int m = 0; m < D; ++m) zz[m] = yi[m];
         field_fwd_wide<D, HUTCH>(net, ws, xc, a.params, lane, w, sgn * ti, zz, ee, f, div);
+        #pragma unroll
+        for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
+        div -= res * (float)D;
         ++nfe;
 #pragma unroll
         for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
@@ -490,17 +502,17 @@ void wide_dopri5_kernel(SolveArgs a) {
 // ---- launchers -----------------------------------------------------------------------------------------------------
 template <int D, bool HUTCH>
 static hipError_t wide_field_t(const float* params, float t, const float* z, const float* e, long rows,
-                               float* f_out, float* nd_out, hipStream_t s) {
+                               float* f_out, float* nd_out, hipStream_t s, float res) {
     const int grid = (int)((rows + kRows - 1) / kRows);
-    hipLaunchKernelGGL((wide_field_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, params, t, z, e, rows, f_out, nd_out);
+    hipLaunchKernelGGL((wide_field_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, params, t, z, e, rows, f_out, nd_out, res);
     return hipGetLastError();
 }
 
 hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, const float* z,
-                             const float* e, long rows, float* f_out, float* nd_out, hipStream_t s) {
-    if (D == 1 && !hutch) return wide_field_t<1, false>(params, t, z, e, rows, f_out, nd_out, s);
-    if (D == 2 && !hutch) return wide_field_t<2, false>(params, t, z, e, rows, f_out, nd_out, s);
-    if (D == 2 && hutch) return wide_field_t<2, true>(params, t, z, e, rows, f_out, nd_out, s);
+                             const float* e, long rows, float* f_out, float* nd_out, hipStream_t s, float res) {
+    if (D == 1 && !hutch) return wide_field_t<1, false>(params, t, z, e, rows, f_out, nd_out, s, res);
+    if (D == 2 && !hutch) return wide_field_t<2, false>(params, t, z, e, rows, f_out, nd_out, s, res);
+    if (D == 2 && hutch) return wide_field_t<2, true>(params, t, z, e, rows, f_out, nd_out, s, res);
     return hipErrorNotSupported;
 }
 

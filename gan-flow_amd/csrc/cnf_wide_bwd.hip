@@ -492,6 +492,7 @@ __global__ __launch_bounds__(kThreads) void wide_aug_kernel(SolveArgs a, const f
                                                             const float* __restrict__ z, const float* __restrict__ a_z,
                                                             const float* __restrict__ a_l, float* __restrict__ f_out,
                                                             float* __restrict__ nd_out, float* __restrict__ vz_out) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = 2 * D + 1;
     __shared__ WideNetLds<D> net;
@@ -514,6 +515,12 @@ __global__ __launch_bounds__(kThreads) void wide_aug_kernel(SolveArgs a, const f
     const float al = valid ? a_l[rr] : 0.f;
     float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
     aug_eval_wide<D, HUTCH>(net, wl[w], xc, part2, a.params, wt, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, region);
+    #pragma unroll
+    for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+        f[m] = fmaf(-res, zz[m], f[m]);
+        vz[m] = fmaf(res, az[m], vz[m]);
+    }
+    div -= res * (float)D;
     if (w == 0 && lane < 16 && valid) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -527,6 +534,7 @@ __global__ __launch_bounds__(kThreads) void wide_aug_kernel(SolveArgs a, const f
 // ---- adjoint solve: the controller of dopri5_bwd_split_kernel with the FSAL d/dtheta bookkeeping on slots --------------
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const float* __restrict__ wt) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = 2 * D + 1;
     constexpr int CE = D + 1;
@@ -601,6 +609,12 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
         }
         aug_eval_wide<D, HUTCH>(net, ws, xc, part2, a.params, wt, lane, w, sgn * ti, zz, ee, az, al, sgn, with_theta, f, div, vz,
                                 region + (size_t)slot_i * kWideSlotF<D>, part);
+        #pragma unroll
+        for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+            f[m] = fmaf(-res, zz[m], f[m]);
+            vz[m] = fmaf(res, az[m], vz[m]);
+        }
+        div -= res * (float)D;
         ++nrun;
 #pragma unroll
         for (int m = 0; m < D; ++m) {

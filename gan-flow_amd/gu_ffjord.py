@@ -17,13 +17,13 @@ from .util import count_parameters, get_logger, makedirs, w_distance
 
 
 def build_model(dim=2, dims=(64, 64, 64), num_blocks=1, time_length=0.5, train_T=True, divergence_fn="brute_force",
-                solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False, layer_type="concatsquash"):
+                solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False, layer_type="concatsquash", residual=False):
     """`num_blocks` CNF blocks over a dim -> dims -> dim concatsquash/tanh ODEnet: the architecture stored in the
     reference's checkpoints.  Other `layer_type`s: see ODEnet."""
     blocks = []
     for _ in range(num_blocks):
         net = ODEnet(tuple(dims), (dim,), strides=None, conv=False, layer_type=layer_type, nonlinearity="tanh")
-        fn = ODEfunc(net, divergence_fn=divergence_fn, residual=False, rademacher=rademacher)
+        fn = ODEfunc(net, divergence_fn=divergence_fn, residual=residual, rademacher=rademacher)
         blocks.append(CNF(fn, T=time_length, train_T=train_T, regularization_fns=(), solver=solver, atol=atol, rtol=rtol))
     return SequentialFlow(blocks)
 

@@ -120,8 +120,6 @@ class ODEfunc(nn.Module):
     def __init__(self, diffeq, divergence_fn="approximate", residual=False, rademacher=False):
         super().__init__()
         assert divergence_fn in ("brute_force", "approximate")
-        if residual:
-            raise NotImplementedError("residual=True is not built into the HIP path (the reference's runs use False)")
         self.diffeq = diffeq
         self.residual = residual
         self.rademacher = rademacher
@@ -145,7 +143,7 @@ class ODEfunc(nn.Module):
 
     def net_desc(self):
         dims = self.diffeq.dims
-        return _native.net_desc(dims[0], self.diffeq.kernel_hidden(), len(dims) - 2, self.uses_hutchinson())
+        return _native.net_desc(dims[0], self.diffeq.kernel_hidden(), len(dims) - 2, self.uses_hutchinson(), self.residual)
 
     def probe(self, like):
         """Hutchinson noise: drawn once per solve (before_odeint resets it) and reused by the adjoint pass."""

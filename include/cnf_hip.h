@@ -47,6 +47,9 @@ typedef struct CnfNetDesc {
 
 enum { CNF_SOLVER_DOPRI5 = 0, CNF_SOLVER_RK4 = 1, CNF_SOLVER_EULER = 2, CNF_SOLVER_MIDPOINT = 3 };   /* 1..3: fixed grid */
 enum { CNF_DIV_EXACT = 0, CNF_DIV_HUTCHINSON = 1 };
+/* OR-ed into CnfNetDesc.divergence: ODEfunc(residual=True) -- the dynamics are dy = f(t, y) - y and the divergence is
+ * reduced by dim accordingly (ffjord/lib/layers/odefunc.py, UPSTREAM-RECALL; the reference's runs use False). */
+enum { CNF_DIV_RESIDUAL = 256 };
 
 /* Solver options: the keyword arguments of torchdiffeq.odeint (rtol, atol, method, options). */
 typedef struct CnfSolverOpts {

@@ -383,3 +383,56 @@ def test_other_hidden_widths_run_zero_padded(hidden):
     assert rel_err(gp, gp_ref) < 2e-4 and rel_err(xp.grad, gx_ref) < 2e-4
     with pytest.raises(NotImplementedError):
         gu_ffjord.FusedTrainStep(mp, xp.detach(), graph=False)
+
+
+@pytest.mark.parametrize("dim,hidden,hutch,rows", [(2, 64, False, 512), (1, 64, False, 5000), (16, 64, True, 300), (2, 256, False, 200),
+                                                   (2, 64, True, 2048)])
+def test_residual_dynamics(dim, hidden, hutch, rows):
+    """ODEfunc(residual=True) (UPSTREAM-RECALL, parity unpinned): dy = f(t, y) - y, divergence - d.
+    Every kernel family applies it where it consumes an evaluation (CNF_DIV_RESIDUAL); training loss, solver steps and
+    gradients against the oracle, plus a fixed-grid evaluation pass."""
+    from gan_flow_amd import gu_ffjord
+    div = "approximate" if hutch else "brute_force"
+    mo = oracle_random_model(dim, seed=19, scale=1.5, divergence_fn=div, hidden_dims=(hidden,) * 3, residual=True)
+    mo.train()
+    mp = gu_ffjord.build_model(dim, dims=(hidden,) * 3, divergence_fn=div, residual=True)
+    mp.load_state_dict(mo.state_dict())
+    mp = mp.to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(rows, dim, generator=g)
+    e = torch.randn(rows, dim, generator=g) if hutch else None
+    if hutch:
+        fo, fp = _odefunc(mo), mp.chain[0].odefunc.odefunc
+        orig = fo.before_odeint
+        fo.before_odeint = lambda e_=None: orig(e=e)
+        origp = fp.before_odeint
+        fp.before_odeint = lambda e_=None: origp(e=e.to(DEV))
+    loss_ref, z_ref, dl_ref, gx_ref, gp_ref, st_ref = _oracle_train_grads(mo, x)
+    xp = x.to(DEV).requires_grad_(True)
+    loss = gu_ffjord.compute_loss(mp, xp)
+    loss.backward()
+    gp = torch.cat([p.grad.reshape(-1) for p in mp.chain[0].odefunc.odefunc.diffeq.parameters()])
+    st = mp.chain[0].last_stats
+    assert (st["forward"].n_accepted, st["forward"].n_rejected) == (st_ref["forward"]["n_accepted"], st_ref["forward"]["n_rejected"])
+    assert (st["backward"].n_accepted, st["backward"].n_rejected) == (st_ref["backward"]["n_accepted"], st_ref["backward"]["n_rejected"])
+    assert abs(loss.item() - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    assert rel_err(gp, gp_ref) < 2e-4 and rel_err(xp.grad, gx_ref) < 2e-4
+    # the residual term matters: the same weights without it give another loss
+    mq = gu_ffjord.build_model(dim, dims=(hidden,) * 3, divergence_fn=div, residual=False)
+    mq.load_state_dict(mo.state_dict())
+    mq = mq.to(DEV).train()
+    if hutch:
+        fq = mq.chain[0].odefunc.odefunc
+        origq = fq.before_odeint
+        fq.before_odeint = lambda e_=None: origq(e=e.to(DEV))
+    assert abs(gu_ffjord.compute_loss(mq, x.to(DEV)).item() - loss_ref) > 1e-2
+    if not hutch:
+        # fixed-grid rk4 in eval mode (the one-tile-per-wave / wide rk4 kernels)
+        mo.eval()
+        mp.eval()
+        for blk in (mo.chain[0], mp.chain[0]):
+            blk.test_solver, blk.solver_options = "rk4", {}
+        with torch.no_grad():
+            z_o, l_o = mo(x[:100], torch.zeros(100, 1))
+        z_p, l_p = mp(x[:100].to(DEV), torch.zeros(100, 1, device=DEV))
+        assert rel_err(z_p, z_o) < 1e-5 and rel_err(l_p, l_o) < 1e-4

@@ -223,3 +223,13 @@ def test_padded_hidden_widths_describe_the_same_net():
     assert ODEnet((100, 100, 100), (2,)).kernel_hidden() == 256
     with pytest.raises(NotImplementedError):
         ODEnet((300, 64, 64), (2,)).kernel_hidden()
+
+
+def test_residual_flag_reaches_the_net_description():
+    from gan_flow_amd import _native
+    from gan_flow_amd.lib.layers.odefunc import ODEfunc, ODEnet
+    plain = ODEfunc(ODEnet((64, 64, 64), (2,)), divergence_fn="brute_force").net_desc()
+    res = ODEfunc(ODEnet((64, 64, 64), (2,)), divergence_fn="approximate", residual=True).train().net_desc()
+    assert plain.divergence == _native.DIV_EXACT
+    assert res.divergence == _native.DIV_HUTCHINSON | _native.DIV_RESIDUAL
+    assert _native.param_count(res) == _native.param_count(plain) == 9224
