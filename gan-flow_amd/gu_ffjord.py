@@ -12,12 +12,13 @@ import time
 import torch
 
 from .gu import make_gu
-from .lib.layers import CNF, ODEfunc, ODEnet, SequentialFlow
+from .lib.layers import CNF, MovingBatchNorm1d, ODEfunc, ODEnet, SequentialFlow
 from .util import count_parameters, get_logger, makedirs, w_distance
 
 
 def build_model(dim=2, dims=(64, 64, 64), num_blocks=1, time_length=0.5, train_T=True, divergence_fn="brute_force",
-                solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False, layer_type="concatsquash", residual=False):
+                solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False, layer_type="concatsquash", residual=False,
+                batch_norm=False, bn_lag=0.0):
     """`num_blocks` CNF blocks over a dim -> dims -> dim concatsquash/tanh ODEnet: the architecture stored in the
     reference's checkpoints.  Other `layer_type`s: see ODEnet."""
     blocks = []
@@ -25,6 +26,11 @@ def build_model(dim=2, dims=(64, 64, 64), num_blocks=1, time_length=0.5, train_T
         net = ODEnet(tuple(dims), (dim,), strides=None, conv=False, layer_type=layer_type, nonlinearity="tanh")
         fn = ODEfunc(net, divergence_fn=divergence_fn, residual=residual, rademacher=rademacher)
         blocks.append(CNF(fn, T=time_length, train_T=train_T, regularization_fns=(), solver=solver, atol=atol, rtol=rtol))
+    if batch_norm:   # build_model_tabular's arrangement: a norm layer first, then one after every CNF block
+        chain = [MovingBatchNorm1d(dim, bn_lag=bn_lag)]
+        for blk in blocks:
+            chain += [blk, MovingBatchNorm1d(dim, bn_lag=bn_lag)]
+        blocks = chain
     return SequentialFlow(blocks)
 
 
@@ -53,7 +59,7 @@ def compute_loss(model, x):
 
 
 def count_nfe(model):
-    return sum(block.num_evals() for block in model.chain)
+    return sum(block.num_evals() for block in model.chain if hasattr(block, "num_evals"))
 
 
 def evaluate_w_distance(model, data, eval_size=100000, chunk=10000, device=None):
@@ -380,6 +386,9 @@ def parse_args(argv=None):
     p.add_argument("--num_blocks", type=int, default=1)
     p.add_argument("--layer_type", type=str, default="concatsquash",
                    choices=["ignore", "concat", "concatcoord", "concat_v2", "squash", "concatsquash"])
+    p.add_argument("--residual", type=eval, default=False, choices=[True, False])
+    p.add_argument("--batch_norm", type=eval, default=False, choices=[True, False])
+    p.add_argument("--bn_lag", type=float, default=0.0)
     p.add_argument("--time_length", type=float, default=0.5)
     p.add_argument("--train_T", type=eval, default=True, choices=[True, False])
     p.add_argument("--divergence_fn", type=str, default="brute_force", choices=["brute_force", "approximate"])
@@ -410,13 +419,17 @@ def main(argv=None):
     data = make_gu(args.gu_num, device="cpu", seed=args.seed, extend_dim=True)
     torch.manual_seed(args.seed)
     model = build_model(2, tuple(int(d) for d in args.dims.split("-")), args.num_blocks, args.time_length, args.train_T,
-                        args.divergence_fn, args.solver, args.atol, args.rtol, layer_type=args.layer_type).to(device)
-    if args.layer_type != "concatsquash" and args.fused:
-        logger.info("layer_type %s: autograd + torch.optim.Adam loop (FusedTrainStep updates concatsquash nets only)" % args.layer_type)
+                        args.divergence_fn, args.solver, args.atol, args.rtol, layer_type=args.layer_type,
+                        residual=args.residual, batch_norm=args.batch_norm, bn_lag=args.bn_lag).to(device)
+    odenets = [blk.odefunc.odefunc.diffeq for blk in model.chain if isinstance(blk, CNF)]
+    if args.fused and (args.layer_type != "concatsquash" or args.batch_norm or any(n.is_padded() for n in odenets)):
+        logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of concatsquash CNF blocks of hidden "
+                    "width 64 / 256 only)")
         args.fused = 0
     if args.step_size:
         for block in model.chain:
-            block.solver_options["step_size"] = args.step_size
+            if isinstance(block, CNF):
+                block.solver_options["step_size"] = args.step_size
     logger.info("parameters: %d" % count_parameters(model))
     model.train()
     fused = optimizer = None
