@@ -7,7 +7,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
+ACTIVATIONS = {"tanh": 0, "softplus": 1, "elu": 2}   # cnf_activation() of the library built for each (csrc/Makefile)
 
 
 class CnfError(RuntimeError):
@@ -41,22 +42,26 @@ STATUS_MESSAGES = {
 }
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
            "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
-           "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms")
+           "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation")
 
 
-def library_path():
-    # CNF_HIP_LIB: another build of the same library (kernel timing experiments, tools/build_variants.sh)
-    return os.environ.get("CNF_HIP_LIB") or os.path.join(_HERE, "libcnf_hip.so")
+def library_path(act="tanh"):
+    """One shared object per ODEnet nonlinearity: libcnf_hip.so (tanh), libcnf_hip_softplus.so, libcnf_hip_elu.so."""
+    if act not in ACTIVATIONS:
+        raise CnfError("nonlinearity %r is not built into the HIP path (have: %s)" % (act, ", ".join(ACTIVATIONS)))
+    # CNF_HIP_LIB: another build of the tanh library (kernel timing experiments, tools/build_variants.sh)
+    if act == "tanh":
+        return os.environ.get("CNF_HIP_LIB") or os.path.join(_HERE, "libcnf_hip.so")
+    return os.path.join(_HERE, "libcnf_hip_%s.so" % act)
 
 
-def load_library():
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = library_path()
+def load_library(act="tanh"):
+    if act in _LIBS:
+        return _LIBS[act]
+    path = library_path(act)
     if not os.path.exists(path):
-        raise CnfError("libcnf_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                       "or `make -C gan-flow_amd/csrc`.  There is no CPU fallback." % path)
+        raise CnfError("%s is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C gan-flow_amd/csrc`.  There is no CPU fallback." % (os.path.basename(path), path))
     lib = ctypes.CDLL(path)
     P, F, I64, SZ, VP = ctypes.c_void_p, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
     ND, SO = ctypes.POINTER(CnfNetDesc), ctypes.POINTER(CnfSolverOpts)
@@ -87,8 +92,18 @@ def load_library():
     lib.cnf_debug_last_kernel_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     lib.cnf_debug_fill_lds.restype = ctypes.c_int
     lib.cnf_debug_fill_lds.argtypes = [ctypes.c_uint32, P, VP]
-    _LIB = lib
+    lib.cnf_activation.restype = ctypes.c_int
+    lib.cnf_activation.argtypes = []
+    if lib.cnf_activation() != ACTIVATIONS[act]:
+        raise CnfError("%s was built for another nonlinearity (cnf_activation() = %d, expected %d)"
+                       % (path, lib.cnf_activation(), ACTIVATIONS[act]))
+    _LIBS[act] = lib
     return lib
+
+
+def _lib_for(net):
+    """The library built for the net's nonlinearity (net_desc() tags the description; plain CnfNetDesc = tanh)."""
+    return load_library(getattr(net, "act", "tanh"))
 
 
 def _check(rc, lib):
@@ -131,7 +146,7 @@ def _workspace(lib, net, rows, device):
 
 
 def workspace_bytes(net, rows):
-    return int(load_library().cnf_workspace_bytes(ctypes.byref(net), rows))
+    return int(_lib_for(net).cnf_workspace_bytes(ctypes.byref(net), rows))
 
 
 def _own_workspace(lib, net, rows, ws):
@@ -142,14 +157,19 @@ def _own_workspace(lib, net, rows, ws):
     return ws
 
 
-def net_desc(dim, hidden, n_hidden, hutchinson, residual=False):
-    """residual: ODEfunc(residual=True), dynamics f(t, y) - y (CNF_DIV_RESIDUAL)."""
-    return CnfNetDesc(int(dim), int(hidden), int(n_hidden),
-                      (DIV_HUTCHINSON if hutchinson else DIV_EXACT) | (DIV_RESIDUAL if residual else 0))
+def net_desc(dim, hidden, n_hidden, hutchinson, residual=False, act="tanh"):
+    """residual: ODEfunc(residual=True), dynamics f(t, y) - y (CNF_DIV_RESIDUAL).  act: the ODEnet's nonlinearity; it is not
+    part of the C struct -- it selects WHICH library the calls with this description go to."""
+    if act not in ACTIVATIONS:
+        raise CnfError("nonlinearity %r is not built into the HIP path (have: %s)" % (act, ", ".join(ACTIVATIONS)))
+    net = CnfNetDesc(int(dim), int(hidden), int(n_hidden),
+                     (DIV_HUTCHINSON if hutchinson else DIV_EXACT) | (DIV_RESIDUAL if residual else 0))
+    net.act = act
+    return net
 
 
 def param_count(net):
-    n = load_library().cnf_param_count(ctypes.byref(net))
+    n = _lib_for(net).cnf_param_count(ctypes.byref(net))
     if n < 0:
         raise CnfError("unsupported net: dim=%d hidden=%d n_hidden=%d divergence=%d"
                        % (net.dim, net.hidden, net.n_hidden, net.divergence))
@@ -197,7 +217,7 @@ def _stats_block(stats, device):
 
 def eval_field(net, params, t, z, e=None):
     """(f, -div) = ODEfunc.forward(t, (z, .)) for a (rows, dim) batch."""
-    lib = load_library()
+    lib = _lib_for(net)
     z = _dev(z, "z")
     rows = z.shape[0]
     params = _dev(params, "params", (param_count(net),))
@@ -212,7 +232,7 @@ def eval_field(net, params, t, z, e=None):
 
 def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None, workspace=None):
     """State (z, logp) at t1 of the CNF ODE started from (x, logp0) at t0.  Returns (z, logp, stats_words)."""
-    lib = load_library()
+    lib = _lib_for(net)
     x = _dev(x, "x")
     rows = x.shape[0]
     params = _dev(params, "params", (param_count(net),))
@@ -230,7 +250,7 @@ def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None, workspace
 
 def eval_aug(net, params, t, z, a_z, a_logp, e=None):
     """One evaluation of the adjoint's augmented dynamics: (f, -div, vjp_z, vjp_params)."""
-    lib = load_library()
+    lib = _lib_for(net)
     z = _dev(z, "z")
     rows = z.shape[0]
     params = _dev(params, "params", (param_count(net),))
@@ -250,7 +270,7 @@ def eval_aug(net, params, t, z, a_z, a_logp, e=None):
 
 def solve_bwd(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e=None, stats=None, workspace=None):
     """Adjoint pass for the interval [t0, t1]: returns (grad_x, grad_logp0, grad_params, stats_words)."""
-    lib = load_library()
+    lib = _lib_for(net)
     z1 = _dev(z1, "z1")
     rows = z1.shape[0]
     params = _dev(params, "params", (param_count(net),))
@@ -275,7 +295,7 @@ def solve_bwd_train(net, params, z1, logp1, grad_z1, grad_logp1, t0, t1, opts, e
     """cnf_solve_bwd_train: adjoint pass + Adam update of `params` (in place) in two kernels.  grad_z1 = grad_logp1 = None:
     the cotangents of the flow's NLL, formed in the kernel; the loss is returned.
     Returns (grad_x, grad_logp0, grad_params or None, loss[1] or None, stats_words)."""
-    lib = load_library()
+    lib = _lib_for(net)
     z1 = _dev(z1, "z1")
     rows = z1.shape[0]
     n = param_count(net)

@@ -437,6 +437,11 @@ int cnf_debug_fill_lds(uint32_t pattern, uint32_t* scratch_word, void* stream) {
     return 0;
 }
 
+#ifndef CNF_ACT
+#define CNF_ACT 0
+#endif
+int cnf_activation(void) { return CNF_ACT; }
+
 int cnf_debug_kernel_timing(int enable) {
     if (enable && !g_ev0) {
         hipError_t err = hipEventCreate(&g_ev0);

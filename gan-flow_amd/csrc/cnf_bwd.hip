@@ -159,8 +159,8 @@ __device__ __forceinline__ void aug_eval(const NetLds<D>& n, const BwdNetLds& nt
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
-            const float dg = (1.0f - x * x) * g[r];
+            const float x = act_f(fmaf(g[r], a[r], c[r]));
+            const float dg = act_d(x) * g[r];
             xs[0][4 * T + r] = x;
             ub[0][4 * T + r] = a[r] + b[r];
             act[0][4 * T + r] = x;
@@ -199,8 +199,8 @@ __device__ __forceinline__ void aug_eval(const NetLds<D>& n, const BwdNetLds& nt
             const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[l + 1][0][fo]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x = tanh_f(fmaf(g[r], a4[0][To][r], c[r]));
-                const float dg = (1.0f - x * x) * g[r];
+                const float x = act_f(fmaf(g[r], a4[0][To][r], c[r]));
+                const float dg = act_d(x) * g[r];
                 xs[l + 1][4 * To + r] = x;
                 ub[l + 1][4 * To + r] = a4[0][To][r] + b[r];
                 act[0][4 * To + r] = x;
@@ -320,7 +320,7 @@ __device__ __forceinline__ void aug_eval(const NetLds<D>& n, const BwdNetLds& nt
             for (int r = 0; r < 4; ++r) {
                 const int s = 4 * T + r;
                 const float x = xs[L][s];
-                const float dx = 1.0f - x * x;
+                const float dx = act_d(x);
                 float pre = dx * cot[0][s];
                 float q2 = 0.f;
 #pragma unroll
@@ -336,7 +336,7 @@ __device__ __forceinline__ void aug_eval(const NetLds<D>& n, const BwdNetLds& nt
                         Uk = w1c[k][r];
                     }
                     const float Xb = cot[1 + k][s];
-                    pre = fmaf(Xb * (g[r] * Uk), -2.0f * x * dx, pre);
+                    pre = fmaf(Xb * (g[r] * Uk), act_dd(x, dx), pre);
                     const float Pb = dx * Xb;
                     q2 = fmaf(Pb, Uk, q2);
                     cot[1 + k][s] = g[r] * Pb;       // Ubar_k
@@ -396,7 +396,7 @@ __device__ __forceinline__ void aug_eval(const NetLds<D>& n, const BwdNetLds& nt
                                 } else {
                                     Uin = w1c[s - 1][r];
                                 }
-                                xin = (1.0f - xi * xi) * gi[r] * Uin;
+                                xin = act_d(xi) * gi[r] * Uin;
                             }
                             sh.tr[0][wave][addr] = w * cot[s][sl];
                             sh.tr[1][wave][addr] = xin;

@@ -66,6 +66,29 @@ __device__ __forceinline__ float tanh_f(float x) {
     return ax < 0.625f ? small : big;
 }
 
+// ---- the ODEnet's nonlinearity ---------------------------------------------------------------------------------------
+// One library per nonlinearity (-DCNF_ACT=..., Makefile): the kernels are written against act_f (the function), act_d
+// (its derivative, from the OUTPUT x = act(u) -- the adjoint keeps x, not u) and act_dd (second derivative, from x and
+// act_d(x)), so that tanh pays nothing for the others.  cnf_activation() reports which one a library was built for.
+#ifndef CNF_ACT
+#define CNF_ACT 0
+#endif
+#if CNF_ACT == 0   // tanh (the reference's runs and checkpoints)
+__device__ __forceinline__ float act_f(float u) { return tanh_f(u); }
+__device__ __forceinline__ float act_d(float x) { return 1.0f - x * x; }
+__device__ __forceinline__ float act_dd(float x, float dx) { return -2.0f * x * dx; }
+#elif CNF_ACT == 1   // softplus, nn.Softplus(beta=1, threshold=20): x = log(1 + e^u); act' = sigmoid(u) = 1 - e^{-x}
+__device__ __forceinline__ float act_f(float u) { return u > 20.0f ? u : log1pf(expf(u)); }
+__device__ __forceinline__ float act_d(float x) { return -expm1f(-x); }
+__device__ __forceinline__ float act_dd(float x, float dx) { return dx * (1.0f - dx); }
+#elif CNF_ACT == 2   // elu, nn.ELU(alpha=1): x = u (u > 0), e^u - 1 otherwise; act' = 1 or x + 1; act'' = 0 or x + 1
+__device__ __forceinline__ float act_f(float u) { return u > 0.0f ? u : expm1f(u); }
+__device__ __forceinline__ float act_d(float x) { return x > 0.0f ? 1.0f : x + 1.0f; }
+__device__ __forceinline__ float act_dd(float x, float dx) { return x > 0.0f ? 0.0f : dx; }
+#else
+#error "CNF_ACT: 0 = tanh, 1 = softplus, 2 = elu"
+#endif
+
 // wave-private LDS hand-off between lanes of ONE wave: program order is enough for the hardware
 // (one in-order LDS queue per wave); this only stops the compiler from moving accesses across it.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -210,8 +233,8 @@ __device__ __forceinline__ void field_fwd(const NetLds<D>& n, WaveLds<D>& ws, in
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], acc[r], c[r]));
-            const float dg = (1.0f - x * x) * g[r];
+            const float x = act_f(fmaf(g[r], acc[r], c[r]));
+            const float dg = act_d(x) * g[r];
             act[0][4 * T + r] = x;
             if (HUTCH) {
                 act[1][4 * T + r] = dg * accu[r];
@@ -248,8 +271,8 @@ __device__ __forceinline__ void field_fwd(const NetLds<D>& n, WaveLds<D>& ws, in
             const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x = tanh_f(fmaf(g[r], acc[0][To][r], c[r]));
-                const float dg = (1.0f - x * x) * g[r];
+                const float x = act_f(fmaf(g[r], acc[0][To][r], c[r]));
+                const float dg = act_d(x) * g[r];
                 act[0][4 * To + r] = x;
 #pragma unroll
                 for (int s = 1; s < NS; ++s) act[s][4 * To + r] = dg * acc[s][To][r];

@@ -99,8 +99,8 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
-            const float dg = (1.0f - x * x) * g[r];
+            const float x = act_f(fmaf(g[r], a[r], c[r]));
+            const float dg = act_d(x) * g[r];
             act[0][r] = x;
             if (HUTCH) {
                 act[1][r] = dg * au[r];
@@ -136,8 +136,8 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
         const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], acc[0][r], c[r]));
-            const float dg = (1.0f - x * x) * g[r];
+            const float x = act_f(fmaf(g[r], acc[0][r], c[r]));
+            const float dg = act_d(x) * g[r];
             act[0][r] = x;
 #pragma unroll
             for (int s = 1; s < NS; ++s) act[s][r] = dg * acc[s][r];
@@ -467,8 +467,8 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
-            const float dg = (1.0f - x * x) * g[r];
+            const float x = act_f(fmaf(g[r], a[r], c[r]));
+            const float dg = act_d(x) * g[r];
             xs[0][r] = x;
             ub[0][r] = a[r] + b[r];
             act[0][r] = x;
@@ -504,8 +504,8 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
         const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[l + 1][0][fo]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a4[0][r], c[r]));
-            const float dg = (1.0f - x * x) * g[r];
+            const float x = act_f(fmaf(g[r], a4[0][r], c[r]));
+            const float dg = act_d(x) * g[r];
             xs[l + 1][r] = x;
             ub[l + 1][r] = a4[0][r] + b[r];
             act[0][r] = x;
@@ -624,7 +624,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float x = xs[L][r];
-            const float dx = 1.0f - x * x;
+            const float dx = act_d(x);
             float pre = dx * cot[0][r];
             float q2 = 0.f;
 #pragma unroll
@@ -640,7 +640,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                     Uk = w1c[k][r];
                 }
                 const float Xb = cot[1 + k][r];
-                pre = fmaf(Xb * (g[r] * Uk), -2.0f * x * dx, pre);
+                pre = fmaf(Xb * (g[r] * Uk), act_dd(x, dx), pre);
                 const float Pb = dx * Xb;
                 q2 = fmaf(Pb, Uk, q2);
                 cot[1 + k][r] = g[r] * Pb;
@@ -687,7 +687,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                             } else {
                                 Uin = w1c[s - 1][r];
                             }
-                            xin = (1.0f - xi * xi) * gi[r] * Uin;
+                            xin = act_d(xi) * gi[r] * Uin;
                         }
                         sb.trA[wave][s][(4 * q + r) * kRows + pos] = w * cot[s][r];
                         sb.trB[buf][s][(fo + r) * kRows + pos] = xin;

@@ -69,9 +69,9 @@ __device__ __forceinline__ void field_fwd16(const NetLds<kD>& n, Wave16Lds& ws, 
         const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[0][1][fo]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
+            const float x = act_f(fmaf(g[r], a[r], c[r]));
             act[0][r] = x;
-            act[1][r] = (1.0f - x * x) * g[r] * au[r];
+            act[1][r] = act_d(x) * g[r] * au[r];
         }
     }
 #pragma unroll
@@ -95,9 +95,9 @@ __device__ __forceinline__ void field_fwd16(const NetLds<kD>& n, Wave16Lds& ws, 
         const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], acc[0][r], c[r]));
+            const float x = act_f(fmaf(g[r], acc[0][r], c[r]));
             act[0][r] = x;
-            act[1][r] = (1.0f - x * x) * g[r] * acc[1][r];
+            act[1][r] = act_d(x) * g[r] * acc[1][r];
         }
     }
     // layer 4: this wave's 16 input features -> partial sums of all 16 outputs, in the state layout
@@ -416,12 +416,12 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
         const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[0][0][fo]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
+            const float x = act_f(fmaf(g[r], a[r], c[r]));
             xs[0][r] = x;
             ub[0][r] = a[r] + b[r];
             U[0][r] = au[r];
             act[0][r] = x;
-            act[1][r] = (1.0f - x * x) * g[r] * au[r];
+            act[1][r] = act_d(x) * g[r] * au[r];
         }
     }
     if (th_lo) {
@@ -450,12 +450,12 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
         const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[l + 1][0][fo]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a4[0][r], c[r]));
+            const float x = act_f(fmaf(g[r], a4[0][r], c[r]));
             xs[l + 1][r] = x;
             ub[l + 1][r] = a4[0][r] + b[r];
             U[l + 1][r] = a4[1][r];
             act[0][r] = x;
-            act[1][r] = (1.0f - x * x) * g[r] * a4[1][r];
+            act[1][r] = act_d(x) * g[r] * a4[1][r];
         }
     }
     {
@@ -557,11 +557,11 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float x = xs[L][r];
-            const float dx = 1.0f - x * x;
+            const float dx = act_d(x);
             const float Uk = U[L][r];
             const float Xb = cot[1][r];
             float pre = dx * cot[0][r];
-            pre = fmaf(Xb * (g[r] * Uk), -2.0f * x * dx, pre);
+            pre = fmaf(Xb * (g[r] * Uk), act_dd(x, dx), pre);
             const float Pb = dx * Xb;
             cot[1][r] = g[r] * Pb;
             s1[r] = pre;
@@ -590,7 +590,7 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
                     sb.trA[wave][0][(4 * q + r) * kRows + pos] = w * cot[0][r];
                     sb.trA[wave][1][(4 * q + r) * kRows + pos] = w * cot[1][r];
                     sb.trB[buf][0][(fo + r) * kRows + pos] = xi;
-                    sb.trB[buf][1][(fo + r) * kRows + pos] = (1.0f - xi * xi) * gi[r] * U[L - 1][r];
+                    sb.trB[buf][1][(fo + r) * kRows + pos] = act_d(xi) * gi[r] * U[L - 1][r];
                 }
             }
             __syncthreads();

@@ -61,8 +61,8 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
-            const float dg = (1.0f - x * x) * g[r];
+            const float x = act_f(fmaf(g[r], a[r], c[r]));
+            const float dg = act_d(x) * g[r];
             act[T][0][r] = x;
             if (HUTCH) {
                 act[T][1][r] = dg * au[r];
@@ -122,8 +122,8 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
             const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][lo]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x = tanh_f(fmaf(g[r], acc[T][0][r], c[r]));
-                const float dg = (1.0f - x * x) * g[r];
+                const float x = act_f(fmaf(g[r], acc[T][0][r], c[r]));
+                const float dg = act_d(x) * g[r];
                 act[T][0][r] = x;
 #pragma unroll
                 for (int s = 1; s < NS; ++s) act[T][s][r] = dg * acc[T][s][r];

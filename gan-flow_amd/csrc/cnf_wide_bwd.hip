@@ -105,8 +105,8 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = tanh_f(fmaf(g[r], a[r], c[r]));
-            const float dg = (1.0f - x * x) * g[r];
+            const float x = act_f(fmaf(g[r], a[r], c[r]));
+            const float dg = act_d(x) * g[r];
             xs[0][T][r] = x;
             ub[0][T][r] = a[r] + b[r];
             act[T][0][r] = x;
@@ -160,8 +160,8 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
             const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[l + 1][0][fo]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x = tanh_f(fmaf(g[r], a4[T][0][r], c[r]));
-                const float dg = (1.0f - x * x) * g[r];
+                const float x = act_f(fmaf(g[r], a4[T][0][r], c[r]));
+                const float dg = act_d(x) * g[r];
                 xs[l + 1][T][r] = x;
                 ub[l + 1][T][r] = a4[T][0][r] + b[r];
                 act[T][0][r] = x;
@@ -268,7 +268,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = xs[L][T][r];
-                const float dx = 1.0f - x * x;
+                const float dx = act_d(x);
                 float pre = dx * cot[0][T][r];
                 float q2 = 0.f;
 #pragma unroll
@@ -284,7 +284,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
                         Uk = w1c[k][T][r];
                     }
                     const float Xb = cot[1 + k][T][r];
-                    pre = fmaf(Xb * (g[r] * Uk), -2.0f * x * dx, pre);
+                    pre = fmaf(Xb * (g[r] * Uk), act_dd(x, dx), pre);
                     const float Pb = dx * Xb;
                     q2 = fmaf(Pb, Uk, q2);
                     cot[1 + k][T][r] = g[r] * Pb;
@@ -335,7 +335,7 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
                                 } else {
                                     Uin = w1c[s - 1][T][r];
                                 }
-                                xin[r] = (1.0f - xi * xi) * gi[r] * Uin;
+                                xin[r] = act_d(xi) * gi[r] * Uin;
                             }
                         }
                         *reinterpret_cast<f32x4*>(&xc.xb[1][s][kWTW * wave + T][lane][0]) = xin;

@@ -18,12 +18,12 @@ from .util import count_parameters, get_logger, makedirs, w_distance
 
 def build_model(dim=2, dims=(64, 64, 64), num_blocks=1, time_length=0.5, train_T=True, divergence_fn="brute_force",
                 solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False, layer_type="concatsquash", residual=False,
-                batch_norm=False, bn_lag=0.0):
+                batch_norm=False, bn_lag=0.0, nonlinearity="tanh"):
     """`num_blocks` CNF blocks over a dim -> dims -> dim concatsquash/tanh ODEnet: the architecture stored in the
     reference's checkpoints.  Other `layer_type`s: see ODEnet."""
     blocks = []
     for _ in range(num_blocks):
-        net = ODEnet(tuple(dims), (dim,), strides=None, conv=False, layer_type=layer_type, nonlinearity="tanh")
+        net = ODEnet(tuple(dims), (dim,), strides=None, conv=False, layer_type=layer_type, nonlinearity=nonlinearity)
         fn = ODEfunc(net, divergence_fn=divergence_fn, residual=residual, rademacher=rademacher)
         blocks.append(CNF(fn, T=time_length, train_T=train_T, regularization_fns=(), solver=solver, atol=atol, rtol=rtol))
     if batch_norm:   # build_model_tabular's arrangement: a norm layer first, then one after every CNF block
@@ -386,6 +386,7 @@ def parse_args(argv=None):
     p.add_argument("--num_blocks", type=int, default=1)
     p.add_argument("--layer_type", type=str, default="concatsquash",
                    choices=["ignore", "concat", "concatcoord", "concat_v2", "squash", "concatsquash"])
+    p.add_argument("--nonlinearity", type=str, default="tanh", choices=["tanh", "softplus", "elu"])
     p.add_argument("--residual", type=eval, default=False, choices=[True, False])
     p.add_argument("--batch_norm", type=eval, default=False, choices=[True, False])
     p.add_argument("--bn_lag", type=float, default=0.0)
@@ -420,7 +421,8 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     model = build_model(2, tuple(int(d) for d in args.dims.split("-")), args.num_blocks, args.time_length, args.train_T,
                         args.divergence_fn, args.solver, args.atol, args.rtol, layer_type=args.layer_type,
-                        residual=args.residual, batch_norm=args.batch_norm, bn_lag=args.bn_lag).to(device)
+                        residual=args.residual, batch_norm=args.batch_norm, bn_lag=args.bn_lag,
+                        nonlinearity=args.nonlinearity).to(device)
     odenets = [blk.odefunc.odefunc.diffeq for blk in model.chain if isinstance(blk, CNF)]
     if args.fused and (args.layer_type != "concatsquash" or args.batch_norm or any(n.is_padded() for n in odenets)):
         logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of concatsquash CNF blocks of hidden "

@@ -21,11 +21,16 @@ def divergence_approx(f, y, e=None):
     raise NotImplementedError("divergence_approx is evaluated inside the fused HIP kernels, not as a Python function")
 
 
+# the nonlinearities a kernel library is built for (csrc/cnf_device.h CNF_ACT, one shared object each): the reference's
+# `--nonlinearity` choices tanh (its runs and checkpoints), softplus and elu; relu / swish / square / identity are not built
+NONLINEARITIES = {"tanh": nn.Tanh, "softplus": nn.Softplus, "elu": nn.ELU}
+
+
 class ODEnet(nn.Module):
     """dim -> hidden_dims -> dim stack of time-conditioned linear layers with tanh between (not after) them.
     layer_type: 'concatsquash' (the reference's runs and checkpoints) or one of its special cases 'ignore', 'concat',
     'concatcoord', 'concat_v2', 'squash' (diffeq_layers/basic.py); 'hyper' and 'blend' have time-dependent weight
-    matrices and are not built.
+    matrices and are not built.  nonlinearity: 'tanh', 'softplus' or 'elu' (one kernel library each).
 
     hidden_dims: three hidden layers.  The kernels are built for widths 64 and 256; any other widths (equal or not, up
     to 256) are presented to them zero-padded to the next kernel width (kernel_hidden): a padded feature has zero
@@ -35,14 +40,16 @@ class ODEnet(nn.Module):
     def __init__(self, hidden_dims, input_shape, strides=None, conv=False, layer_type="concatsquash",
                  nonlinearity="tanh", num_squeeze=0):
         super().__init__()
-        if conv or layer_type not in LAYER_TYPES or nonlinearity != "tanh" or num_squeeze != 0:
-            raise NotImplementedError("the HIP path is built for layer_type in %s, nonlinearity='tanh', no conv/squeeze "
-                                      "(got layer_type=%r, nonlinearity=%r)" % (sorted(LAYER_TYPES), layer_type, nonlinearity))
+        if conv or layer_type not in LAYER_TYPES or nonlinearity not in NONLINEARITIES or num_squeeze != 0:
+            raise NotImplementedError("the HIP path is built for layer_type in %s, nonlinearity in %s, no conv/squeeze "
+                                      "(got layer_type=%r, nonlinearity=%r)"
+                                      % (sorted(LAYER_TYPES), sorted(NONLINEARITIES), layer_type, nonlinearity))
         self.num_squeeze = num_squeeze
         self.layer_type = layer_type
+        self.nonlinearity = nonlinearity
         dims = (int(input_shape[0]),) + tuple(int(h) for h in hidden_dims) + (int(input_shape[0]),)
         self.layers = nn.ModuleList(LAYER_TYPES[layer_type](a, b) for a, b in zip(dims[:-1], dims[1:]))
-        self.activation_fns = nn.ModuleList(nn.Tanh() for _ in range(len(dims) - 2))
+        self.activation_fns = nn.ModuleList(NONLINEARITIES[nonlinearity]() for _ in range(len(dims) - 2))
 
     @property
     def dims(self):
@@ -143,7 +150,8 @@ class ODEfunc(nn.Module):
 
     def net_desc(self):
         dims = self.diffeq.dims
-        return _native.net_desc(dims[0], self.diffeq.kernel_hidden(), len(dims) - 2, self.uses_hutchinson(), self.residual)
+        return _native.net_desc(dims[0], self.diffeq.kernel_hidden(), len(dims) - 2, self.uses_hutchinson(), self.residual,
+                                getattr(self.diffeq, "nonlinearity", "tanh"))
 
     def probe(self, like):
         """Hutchinson noise: drawn once per solve (before_odeint resets it) and reused by the adjoint pass."""

@@ -283,3 +283,19 @@ def test_build_model_with_batch_norm_layers():
     kinds = [type(l) for l in m.chain]
     assert kinds == [MovingBatchNorm1d, CNF, MovingBatchNorm1d, CNF, MovingBatchNorm1d]
     assert m.chain[0].bn_lag == 0.1
+
+
+def test_one_library_per_nonlinearity():
+    """libcnf_hip.so / libcnf_hip_softplus.so / libcnf_hip_elu.so export the same C ABI and say what they were built for."""
+    from gan_flow_amd import _native
+    from gan_flow_amd.lib.layers.odefunc import ODEfunc, ODEnet
+    for act, code in _native.ACTIVATIONS.items():
+        lib = _native.load_library(act)
+        assert lib.cnf_activation() == code
+        for name in _native.EXPORTS:
+            assert hasattr(lib, name), (act, name)
+        assert ODEfunc(ODEnet((64, 64, 64), (2,), nonlinearity=act), divergence_fn="brute_force").net_desc().act == act
+    with pytest.raises(NotImplementedError):
+        ODEnet((64, 64, 64), (2,), nonlinearity="swish")
+    with pytest.raises(_native.CnfError):
+        _native.net_desc(2, 64, 3, False, act="relu")
