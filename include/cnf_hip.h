@@ -1,5 +1,6 @@
 /*
- * cnf_hip.h -- C ABI of libcnf_hip.so: the MI355X (gfx950) FFJORD CNF hot path.
+ * cnf_hip.h -- C ABI of libcnf_hip.so (and of its siblings built for other nonlinearities, see cnf_activation):
+ * the MI355X (gfx950) FFJORD CNF hot path.
  *
  * The reference has no native code and no FFI: its hot path is Python calling torchdiffeq
  *     odeint_adjoint(odefunc, (z, logpz), integration_times, atol=[a,a], rtol=[r,r], method=solver)
@@ -35,14 +36,15 @@
 extern "C" {
 #endif
 
-/* ODEnet description: dim -> hidden x n_hidden -> dim, ConcatSquashLinear layers, tanh between layers.
+/* ODEnet description: dim -> hidden x n_hidden -> dim, ConcatSquashLinear layers, the library's nonlinearity (tanh for
+ * libcnf_hip.so) between layers.
  * Replaces the Python object graph ODEfunc(ODEnet(...)).            */
 typedef struct CnfNetDesc {
     int32_t dim;        /* data dimension d: 1, 2 or 16                                          */
-    int32_t hidden;     /* hidden width: 64, or 256 (forward entry points only, dim 1 | 2)       */
+    int32_t hidden;     /* hidden width: 64, or 256 (dim 1 | 2; narrower nets: zero-padded by the caller) */
     int32_t n_hidden;   /* number of hidden layers: 3                                            */
     int32_t divergence; /* 0 = brute force (exact trace, `divergence_bf`), 1 = Hutchinson
-                           (`divergence_approx`, probe `e` fixed for the whole solve)           */
+                           (`divergence_approx`, probe `e` fixed for the whole solve); | CNF_DIV_RESIDUAL */
 } CnfNetDesc;
 
 enum { CNF_SOLVER_DOPRI5 = 0, CNF_SOLVER_RK4 = 1, CNF_SOLVER_EULER = 2, CNF_SOLVER_MIDPOINT = 3 };   /* 1..3: fixed grid */
