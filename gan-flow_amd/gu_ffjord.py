@@ -440,6 +440,9 @@ def main(argv=None):
         fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay)
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=True)
+        for block in model.chain:          # one training per GPU: the adjoint may use both halves of the chip
+            if isinstance(block, CNF):
+                block.spread_adjoint = True
     start_itr = 0
     if args.resume:
         ck = torch.load(args.resume, map_location=device, weights_only=True)

@@ -62,6 +62,8 @@ class CNF(nn.Module):
         # not in the reference: knobs of the fused integrator
         self.tile_rows = 0          # 0 = one step size for the whole batch (reference semantics); 16 = per-tile control
         self.sync_stats = True      # read the solver status back after every solve (one host sync, as the reference has)
+        self.spread_adjoint = False  # backward(): CNF_FLAG_SPREAD, two workgroups per 16-row tile (include/cnf_hip.h); same
+                                     # gradients, faster for batches <= 2048 rows; not for solves sharing a GPU with others
         self.last_stats = {}
 
     # ------------------------------------------------------------------------------------------------
@@ -104,7 +106,8 @@ class CNF(nn.Module):
             solver, atol, rtol, options = self.solver, self.atol, self.rtol, self.solver_options
         else:
             solver, atol, rtol, options = self.test_solver, self.test_atol, self.test_rtol, {}
-        opts = _native.make_opts(solver, rtol, atol, options.get("step_size"), self.tile_rows, options.get("max_num_steps", 0))
+        opts = _native.make_opts(solver, rtol, atol, options.get("step_size"), self.tile_rows, options.get("max_num_steps", 0),
+                                 flags=_native.FLAG_SPREAD if self.spread_adjoint else 0)
         return inner.net_desc(), t0, t1, opts, inner.probe(z)
 
     def forward(self, z, logpz=None, integration_times=None, reverse=False):

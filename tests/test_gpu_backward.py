@@ -169,6 +169,13 @@ def test_module_training_step_fills_parameter_grads():
     assert nfe_total == nfe_total_ref
     assert rel_err(gp, gp_ref) < 2e-4 and rel_err(xp.grad, gx_ref) < 2e-4
     assert mp.chain[0].sqrt_end_time.grad is None       # the end time is detached, as in the reference
+    # the same step with two workgroups per tile in the adjoint (CNF.spread_adjoint): identical gradients
+    mp.zero_grad(set_to_none=True)
+    mp.chain[0].spread_adjoint = True
+    xs = x.to(DEV).requires_grad_(True)
+    gu_ffjord.compute_loss(mp, xs).backward()
+    gs = torch.cat([p.grad.reshape(-1) for p in mp.chain[0].odefunc.odefunc.diffeq.parameters()])
+    assert torch.equal(gs, gp) and torch.equal(xs.grad, xp.grad)
 
 
 @pytest.mark.parametrize("layer_type", ["ignore", "concat", "concat_v2", "squash"])
