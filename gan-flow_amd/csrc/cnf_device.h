@@ -377,6 +377,10 @@ struct GridSync {
     unsigned long long* gran;  // [2][nwg*4]
     int nwg;
     unsigned epoch;
+#ifdef CNF_PROF_SYNC   // timing experiment (tools/build_variants.sh sync "-DCNF_PROF_SYNC"): wave 0's view of the reductions
+    unsigned long long t_total = 0, t_first = 0, t_pre = 0, t_post = 0;
+    unsigned n_sweeps = 0, n_red = 0, n_self_first = 0;
+#endif
 };
 
 constexpr unsigned kSpinLimit = 1u << 24;
@@ -385,6 +389,10 @@ constexpr unsigned kSpinLimit = 1u << 24;
 // ALLQ: all four lane quarters of a wave carry contributions (cnf_split16.hip), not just quarter 0.
 template <bool ALLQ = false>
 __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], int w, int lane) {
+#ifdef CNF_PROF_SYNC
+    const unsigned long long t_in = clock64();
+    unsigned long long t_done = t_in;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = ALLQ ? xq_sum_f64(row16_sum(v[i])) : row16_sum(v[i]);
     if (lane == 0) {
@@ -395,6 +403,11 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
     if (w == 0) {
         double s = 0.0;
         if (lane < 4) s = red.part[0][lane] + red.part[1][lane] + red.part[2][lane] + red.part[3][lane];
+#ifdef CNF_PROF_SYNC
+        const unsigned long long tp0 = clock64();
+        gs.t_pre += tp0 - t_in;
+        bool first_sweep = true;
+#endif
 #ifdef CNF_EXP_NO_GRIDSYNC
         if (false) {
 #else
@@ -427,9 +440,28 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
                     ok &= (unsigned)(x[k] >> 32) == gs.epoch;
                     acc += (double)__uint_as_float((unsigned)x[k]);   // padding entries carry +0.0f
                 }
+#ifdef CNF_PROF_SYNC
+                gs.n_sweeps += 1;
+                if (first_sweep) {
+                    first_sweep = false;
+                    gs.t_first += clock64() - tp0;
+                    // was this workgroup's own first granule (slot blockIdx.x * 4) already visible to it?
+                    const int g0 = blockIdx.x * 4;
+                    unsigned long long mine = 0;
+#pragma unroll
+                    for (int k = 0; k < kPerLane; ++k) mine = (g0 / 64 == k) ? x[k] : mine;
+                    const unsigned tag = (unsigned)(__shfl(mine, g0 % 64) >> 32);
+                    gs.n_self_first += tag == gs.epoch;
+                }
+#endif
                 if (__all(ok)) { done = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
+#ifdef CNF_PROF_SYNC
+            t_done = clock64();
+            gs.t_total += t_done - tp0;
+            gs.n_red += 1;
+#endif
             if (!done && lane == 0) red.status = CNF_ERR_SYNC_TIMEOUT;
             // lanes with equal (lane & 3) hold partial sums of the same quantity; lanes 0..3 need the totals
             acc += dpp_mov_f64<0x124>(acc);   // row_ror:4
@@ -443,6 +475,9 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = red.tot[i];
+#ifdef CNF_PROF_SYNC
+    if (w == 0) gs.t_post += clock64() - t_done;
+#endif
     return red.status == 0;
 }
 

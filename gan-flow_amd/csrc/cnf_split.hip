@@ -372,6 +372,13 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
     }
     grid_cleanup(gs, red, tid);
     write_stats_global(a.stats, status, nfe, nacc, nrej, nfe, (float)dt, a.rows, tid);
+#ifdef CNF_PROF_SYNC
+    if ((blockIdx.x == 0 || blockIdx.x == 77) && tid == 0 && nfe > 100)
+        printf("fwd sync wg %d: reductions %u, clocks/reduction: entry -> publish %.0f, publish -> all seen %.0f (end of first sweep "
+               "%.0f), all seen -> exit %.0f; sweeps/reduction %.2f, own granule seen in first sweep %.2f\n", (int)blockIdx.x,
+               gs.n_red, (double)gs.t_pre / gs.n_red, (double)gs.t_total / gs.n_red, (double)gs.t_first / gs.n_red,
+               (double)gs.t_post / gs.n_red, (double)gs.n_sweeps / gs.n_red, (double)gs.n_self_first / gs.n_red);
+#endif
 #ifdef CNF_PROF_CYCLES
     if (blockIdx.x == 0 && tid == 0 && nfe > 100) {
         printf("fwd prof nfe %d cycles/eval:", nfe);
