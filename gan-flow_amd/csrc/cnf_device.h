@@ -343,6 +343,42 @@ __device__ __forceinline__ void stage_coeffs(int stage, float& alpha, float (&b)
     }
 }
 
+// The state at which stage `stage` (1..6) evaluates the dynamics, y0 + dt * sum_{s < stage} a[stage][s] k_s, reading
+// exactly the slopes that stage uses (3.5 of 6 on average; stage_coeffs + a six-term loop reads and multiplies all six,
+// the unused ones by zero).  k(s, c): slope of stage s, component c.  Returns the stage's time fraction alpha.
+// Same sums as the six-term form up to the sign of a zero.
+template <int N, int C, class K>
+__device__ __forceinline__ void stage_sum(const float (&w)[N], float dtf, const float (&y0)[C], K& k, float (&yi)[C]) {
+    float dw[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) dw[s] = dtf * w[s];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float acc = dw[0] * k(0, c);
+#pragma unroll
+        for (int s = 1; s < N; ++s) acc += dw[s] * k(s, c);
+        yi[c] = y0[c] + acc;
+    }
+}
+
+template <int C, class K>
+__device__ __forceinline__ float stage_state(int stage, float dtf, const float (&y0)[C], K k, float (&yi)[C]) {
+    switch (stage) {
+        case 1: { const float w[1] = {(float)(1.0 / 5)}; stage_sum(w, dtf, y0, k, yi); return (float)(1.0 / 5); }
+        case 2: { const float w[2] = {(float)(3.0 / 40), (float)(9.0 / 40)}; stage_sum(w, dtf, y0, k, yi); return (float)(3.0 / 10); }
+        case 3: { const float w[3] = {(float)(44.0 / 45), (float)(-56.0 / 15), (float)(32.0 / 9)}; stage_sum(w, dtf, y0, k, yi);
+                  return (float)(4.0 / 5); }
+        case 4: { const float w[4] = {(float)(19372.0 / 6561), (float)(-25360.0 / 2187), (float)(64448.0 / 6561), (float)(-212.0 / 729)};
+                  stage_sum(w, dtf, y0, k, yi); return (float)(8.0 / 9); }
+        case 5: { const float w[5] = {(float)(9017.0 / 3168), (float)(-355.0 / 33), (float)(46732.0 / 5247), (float)(49.0 / 176),
+                                      (float)(-5103.0 / 18656)};
+                  stage_sum(w, dtf, y0, k, yi); return 1.f; }
+        default: { const float w[6] = {(float)(35.0 / 384), 0.f, (float)(500.0 / 1113), (float)(125.0 / 192), (float)(-2187.0 / 6784),
+                                       (float)(11.0 / 84)};
+                   stage_sum(w, dtf, y0, k, yi); return 1.f; }
+    }
+}
+
 // stage_coeffs multiplies the slopes of stages that have not been evaluated yet by a zero weight, so those slots must
 // hold finite numbers from the start: LDS keeps whatever the previous kernel on the CU left there, and 0 * NaN = NaN.
 // Call before the kernel's first workgroup barrier; `n_ws` = number of per-wave blocks in `wl`.

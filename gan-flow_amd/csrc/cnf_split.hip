@@ -335,16 +335,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
             phase = PH_STAGE;
             pr.mark(16);
         }
-        float alpha_, bc_[6];
-        stage_coeffs(stage, alpha_, bc_);
-        ti = t0f + alpha_ * dtf;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            float acc = 0.f;
-#pragma unroll
-            for (int s = 0; s < 6; ++s) acc += (dtf * bc_[s]) * ws.kst[s][c][j];   // zero weights past the current stage
-            yi[c] = y0[c] + acc;
-        }
+        ti = t0f + stage_state(stage, dtf, y0, [&](int s, int c) { return ws.kst[s][c][j]; }, yi) * dtf;
     }
 
     if (status == 0) {
@@ -1095,16 +1086,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
 #pragma unroll
             for (int c = 0; c < C; ++c) yi[c] = y0[c];
         } else {
-            float alpha_, bc_[6];
-            stage_coeffs(stage, alpha_, bc_);
-            ti = t0f + alpha_ * dtf;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float s_ = 0.f;
-#pragma unroll
-                for (int s = 0; s < 6; ++s) s_ += (dtf * bc_[s]) * ws.kst[s][c][j];   // zero weights past the current stage
-                yi[c] = y0[c] + s_;
-            }
+            ti = t0f + stage_state(stage, dtf, y0, [&](int s, int c) { return ws.kst[s][c][j]; }, yi) * dtf;
         }
     }
 
