@@ -55,6 +55,9 @@ __device__ __forceinline__ float sigmoid_f(float a) {
 }
 // tanh accurate to ~1 ulp: odd minimax polynomial below 0.625 (Cephes tanhf), 1 - 2/(e^{2|x|}+1) above.
 __device__ __forceinline__ float tanh_f(float x) {
+#ifdef CNF_EXP_FAST_TANH   // timing experiment: 1 - 2 / (e^{2x} + 1) alone (absolute error ~2e-7, 5 instructions instead of ~18)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.885390081777927f) + 1.0f), 1.0f);
+#endif
     const float ax = fabsf(x);
     const float x2 = x * x;
     float p = fmaf(x2, -5.70498872745e-3f, 2.06390887954e-2f);
