@@ -191,8 +191,8 @@ __device__ inline void stage_net(NetLds<D>& n, const float* __restrict__ p, int 
 }
 
 // gates of all four layers at time t, one feature per lane, into the wave's scratch
-template <int D>
-__device__ __forceinline__ void compute_gates(const NetLds<D>& n, WaveLds<D>& ws, int lane, float t) {
+template <class N, class WS>
+__device__ __forceinline__ void compute_gates(const N& n, WS& ws, int lane, float t) {
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
         const float g = sigmoid_f(fmaf(n.vec[l][2][lane], t, n.vec[l][3][lane]));
@@ -284,6 +284,194 @@ __device__ __forceinline__ void field_fwd(const NetLds<D>& n, WaveLds<D>& ws, in
     }
     // layer 4: 64 -> d on the vector ALU; each lane holds 16 of the 64 features of its row
     float pf[D], pd[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) pf[m] = pd[m] = 0.f;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const int fo = 16 * T + 4 * q;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&n.w4[m][fo]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[m] = fmaf(w[r], act[0][4 * T + r], pf[m]);
+                pd[m] = fmaf(w[r], act[HUTCH ? 1 : 1 + m][4 * T + r], pd[m]);
+            }
+        }
+    }
+    div = 0.f;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        const float g4 = ws.gate4[0][m];
+        f[m] = fmaf(g4, xq_sum(pf[m]), ws.gate4[1][m]);
+        const float dm = g4 * xq_sum(pd[m]);
+        div += HUTCH ? dm * e[m] : dm;
+    }
+}
+
+// ---- the same dynamics with the hidden layers on the bf16 matrix pipe, operands split in three -----------------------
+// Throughput evaluation (tile-local dopri5, d <= 2).  On gfx950 the fp32 MFMA occupies the vector ALU for its whole
+// duration (tools/mfma_valu_overlap.hip); v_mfma_f32_16x16x32_bf16 runs beside it and does 8x the FLOP per clock.  Every
+// fp32 operand is written as hi + mid + lo, three TRUNCATED bf16 pieces (24 significant bits, every subtraction exact);
+// of the nine piece products the six of weight >= 2^-16 are kept (hh, hm, mh, hl, mm, lh: the dropped ones are below
+// 2^-24 of the product) and summed in fp32 by the matrix core, smallest first.  Measured on one 64 -> 64 layer against
+// float64 (tools/bf16_split_layer.hip): rms error 6.3e-8 of the rms value -- the k-ordered fp32 fmaf chain of
+// v_mfma_f32_16x16x4_f32 has 1.5e-7 -- in 993 instead of 1 649 clocks per wave, split included.
+// The C/D register layout of a layer's output is a valid B operand of the 16x16x32 instruction as well: lane (q, j)
+// supplies 8 consecutive k, and k order is free as long as the weight image uses the same one -- k-step ks takes the
+// lane's features 16T + 4q + r of T = 2ks, 2ks+1, i.e. act[8ks .. 8ks+7].
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_bf16(float x, uint32_t (&p)[3]) {   // pieces in the upper 16 bits
+    p[0] = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(p[0]);
+    p[1] = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(p[1]);
+    p[2] = __float_as_uint(r2) & 0xffff0000u;
+}
+__device__ __forceinline__ bf16x8 mfma_b16_operand(const uint32_t (&pc)[8][3], int p) {
+    const u32x4 v = {(pc[0][p] >> 16) | pc[1][p], (pc[2][p] >> 16) | pc[3][p], (pc[4][p] >> 16) | pc[5][p],
+                     (pc[6][p] >> 16) | pc[7][p]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ f32x4 mfma_b16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int D>
+struct alignas(16) NetLdsB16 {
+    uint32_t wimg16[2][4][2][3][64][4];   // layers 2,3: [layer][Tout][k-step][piece][lane] = 8 bf16 of W[16Tout+(lane&15)][k order above]
+    float w1[D][kH];
+    float w4[D][kH];
+    float vec[3][4][kH];
+    float vec4[4][16];
+};
+
+template <int D>
+__device__ inline void stage_net_b16(NetLdsB16<D>& n, const float* __restrict__ p, int tid, int nthreads) {
+    const ParamLayout L = make_layout(D, kH);
+    for (int idx = tid; idx < 2 * 4 * 2 * 64 * 4; idx += nthreads) {
+        const int v = idx & 3, lane = (idx >> 2) & 63, ks = (idx >> 8) & 1, To = (idx >> 9) & 3, l = idx >> 11;
+        const int row = 16 * To + (lane & 15);
+        uint32_t lo[3], hi[3];
+        const int e0 = 2 * v, e1 = 2 * v + 1;
+        split3_bf16(p[L.w(1 + l) + row * kH + 16 * (2 * ks + (e0 >> 2)) + 4 * (lane >> 4) + (e0 & 3)], lo);
+        split3_bf16(p[L.w(1 + l) + row * kH + 16 * (2 * ks + (e1 >> 2)) + 4 * (lane >> 4) + (e1 & 3)], hi);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) n.wimg16[l][To][ks][pc][lane][v] = (lo[pc] >> 16) | hi[pc];
+    }
+    for (int idx = tid; idx < D * kH; idx += nthreads) {
+        const int m = idx / kH, i = idx % kH;
+        n.w1[m][i] = p[L.w(0) + i * D + m];
+        n.w4[m][i] = p[L.w(3) + m * kH + i];
+    }
+    for (int idx = tid; idx < 3 * kH; idx += nthreads) {
+        const int l = idx / kH, i = idx % kH;
+        n.vec[l][0][i] = p[L.b(l) + i];
+        n.vec[l][1][i] = p[L.hb(l) + i];
+        n.vec[l][2][i] = p[L.wg(l) + i];
+        n.vec[l][3][i] = p[L.bg(l) + i];
+    }
+    if (tid < 16) {
+        const bool in = tid < D;
+        n.vec4[0][tid] = in ? p[L.b(3) + tid] : 0.f;
+        n.vec4[1][tid] = in ? p[L.hb(3) + tid] : 0.f;
+        n.vec4[2][tid] = in ? p[L.wg(3) + tid] : 0.f;
+        n.vec4[3][tid] = in ? p[L.bg(3) + tid] : 0.f;
+    }
+}
+
+template <int D, bool HUTCH>
+__device__ __forceinline__ void field_fwd_b16(const NetLdsB16<D>& n, WaveLds<D>& ws, int lane, float t,
+                                              const float (&z)[D], const float (&e)[D], float (&f)[D], float& div) {
+    constexpr int NT = HUTCH ? 1 : D;
+    constexpr int NS = NT + 1;
+    const int q = lane >> 4;
+    compute_gates(n, ws, lane, t);
+
+    float act[NS][16];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {   // layer 1, as field_fwd
+        const int fo = 16 * T + 4 * q;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[0][0][fo]);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[0][1][fo]);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accu = {0.f, 0.f, 0.f, 0.f};
+        f32x4 wcol[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            wcol[m] = *reinterpret_cast<const f32x4*>(&n.w1[m][fo]);
+            acc += wcol[m] * z[m];
+            if (HUTCH) accu += wcol[m] * e[m];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = act_f(fmaf(g[r], acc[r], c[r]));
+            const float dg = act_d(x) * g[r];
+            act[0][4 * T + r] = x;
+            if (HUTCH) {
+                act[1][4 * T + r] = dg * accu[r];
+            } else {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) act[1 + m][4 * T + r] = dg * wcol[m][r];
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {   // layers 2, 3: six bf16 piece products per k-step, all streams share the weight pieces
+        f32x4 acc[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int To = 0; To < 4; ++To) acc[s][To] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 b[NS][3];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                uint32_t pc[8][3];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) split3_bf16(act[s][8 * ks + k], pc[k]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[s][p] = mfma_b16_operand(pc, p);
+            }
+#pragma unroll
+            for (int To = 0; To < 4; ++To) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&n.wimg16[l][To][ks][p][lane][0]));
+                // smallest products first; consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][To] = mfma_b16(a[0], b[s][2], acc[s][To]);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][To] = mfma_b16(a[2], b[s][0], acc[s][To]);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][To] = mfma_b16(a[1], b[s][1], acc[s][To]);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][To] = mfma_b16(a[0], b[s][1], acc[s][To]);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][To] = mfma_b16(a[1], b[s][0], acc[s][To]);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][To] = mfma_b16(a[0], b[s][0], acc[s][To]);
+            }
+        }
+#pragma unroll
+        for (int To = 0; To < 4; ++To) {
+            const int fo = 16 * To + 4 * q;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = act_f(fmaf(g[r], acc[0][To][r], c[r]));
+                const float dg = act_d(x) * g[r];
+                act[0][4 * To + r] = x;
+#pragma unroll
+                for (int s = 1; s < NS; ++s) act[s][4 * To + r] = dg * acc[s][To][r];
+            }
+        }
+    }
+    float pf[D], pd[D];   // layer 4, as field_fwd
 #pragma unroll
     for (int m = 0; m < D; ++m) pf[m] = pd[m] = 0.f;
 #pragma unroll

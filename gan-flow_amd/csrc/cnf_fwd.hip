@@ -4,6 +4,8 @@
 // (controller restated from Appendix B).  One persistent launch
 // integrates the whole interval: weights are staged in LDS once, each wave keeps the state of its
 // 16 rows in registers, the Runge-Kutta slopes in wave-private LDS.
+#include <type_traits>
+
 #include "cnf_launch.h"
 
 namespace cnf {
@@ -16,10 +18,18 @@ __global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict
                                                          const float* __restrict__ z, const float* __restrict__ e,
                                                          long rows, float* __restrict__ f_out,
                                                          float* __restrict__ neg_div_out, float res) {
+#if defined(CNF_DBG_FIELD_B16)   // debugging aid: cnf_eval_field through the bf16-split layers (tools/build_variants.sh)
+    __shared__ NetLdsB16<D> net;
+#else
     __shared__ NetLds<D> net;
+#endif
     __shared__ WaveLds<D> wl[kNW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+#if defined(CNF_DBG_FIELD_B16)
+    stage_net_b16(net, params, tid, kThreads);
+#else
     stage_net(net, params, tid);
+#endif
     __syncthreads();
     const long base = ((long)blockIdx.x * kNW + w) * kRows;
     if (base >= rows) return;
@@ -31,7 +41,11 @@ __global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict
         zz[m] = z[rr * D + m];
         ee[m] = HUTCH ? e[rr * D + m] : 0.f;
     }
+#if defined(CNF_DBG_FIELD_B16)
+    field_fwd_b16<D, HUTCH>(net, wl[w], lane, t, zz, ee, f, div);
+#else
     field_fwd<D, HUTCH>(net, wl[w], lane, t, zz, ee, f, div);
+#endif
     #pragma unroll
     for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
     div -= res * (float)D;
@@ -53,6 +67,20 @@ __global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict
 #define CNF_EVAL_NW 4
 #endif
 constexpr int kEvalWaves = CNF_EVAL_WAVES, kEvalNW = CNF_EVAL_NW;
+// Tile-local dopri5 at d <= 2 runs its hidden layers on the bf16 matrix pipe with split operands (field_fwd_b16,
+// cnf_device.h).  Its three-piece weight image is 48 KB: six waves share one, so that two workgroups (twelve waves =
+// three per SIMD) fit the 160 KB of a compute unit.  -DCNF_EVAL_BF16=0 builds the fp32-MFMA kernel instead.
+#ifndef CNF_EVAL_BF16
+#define CNF_EVAL_BF16 1
+#endif
+#ifndef CNF_EVAL_B16_NW
+#define CNF_EVAL_B16_NW 4
+#endif
+#ifndef CNF_EVAL_B16_WAVES
+#define CNF_EVAL_B16_WAVES 2
+#endif
+constexpr bool kEvalB16 = CNF_EVAL_BF16 != 0;
+constexpr int kEvalB16NW = CNF_EVAL_B16_NW, kEvalB16Waves = CNF_EVAL_B16_WAVES;
 
 // ------------------------------------------------------------------------------------------------
 // fixed-grid RK4, 3/8 rule (Appendix B.6).  No cross-row coupling: waves are independent.
@@ -154,18 +182,23 @@ void rk4_kernel(SolveArgs a) {
 //   GLOBAL = false: every 16-row tile (one wave) runs its own controller; waves never synchronise
 // The loop is a small state machine around ONE inlined copy of the dynamics.
 // ------------------------------------------------------------------------------------------------
-template <int D, bool HUTCH, bool GLOBAL, int NW>
+template <int D, bool HUTCH, bool GLOBAL, int NW, bool B16 = false>
 __global__ __launch_bounds__(NW * 64)
-    __attribute__((amdgpu_waves_per_eu(GLOBAL || D > 2 ? 1 : kEvalWaves, GLOBAL || D > 2 ? 8 : kEvalWaves)))
+    __attribute__((amdgpu_waves_per_eu(GLOBAL || D > 2 ? 1 : (B16 ? kEvalB16Waves : kEvalWaves),
+                                       GLOBAL || D > 2 ? 8 : (B16 ? kEvalB16Waves : kEvalWaves))))
     void dopri5_kernel(SolveArgs a) {
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
-    __shared__ NetLds<D> net;
+    __shared__ typename std::conditional<B16, NetLdsB16<D>, NetLds<D>>::type net;
     __shared__ WaveLds<D> wl[NW];
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     constexpr int C = D + 1;
     if (tid == 0) red.status = 0;
-    stage_net(net, a.params, tid, NW * 64);
+    if constexpr (B16) {
+        stage_net_b16(net, a.params, tid, NW * 64);
+    } else {
+        stage_net(net, a.params, tid, NW * 64);
+    }
     zero_slopes(wl, NW, tid, NW * 64);
     __syncthreads();
     const long base = ((long)blockIdx.x * NW + w) * kRows;
@@ -212,7 +245,11 @@ __global__ __launch_bounds__(NW * 64)
         bool restart = false;
 #pragma unroll
         for (int m = 0; m < D; ++m) zz[m] = yi[m];
-        field_fwd<D, HUTCH>(net, ws, lane, sgn * ti, zz, ee, f, div);
+        if constexpr (B16) {
+            field_fwd_b16<D, HUTCH>(net, ws, lane, sgn * ti, zz, ee, f, div);
+        } else {
+            field_fwd<D, HUTCH>(net, ws, lane, sgn * ti, zz, ee, f, div);
+        }
         #pragma unroll
         for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
         div -= res * (float)D;
@@ -408,9 +445,10 @@ static hipError_t launch_solve_t(const SolveArgs& a, int solver, bool global, hi
     } else if (global) {
         hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, true, kNW>), dim3(grid), dim3(kThreads), 0, s, a);
     } else {
-        constexpr int NW = D > 2 ? kNW : kEvalNW;
+        constexpr bool B16 = kEvalB16 && D <= 2;
+        constexpr int NW = D > 2 ? kNW : (B16 ? kEvalB16NW : kEvalNW);
         const int g = (int)((a.rows + NW * kRows - 1) / (NW * kRows));
-        hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, false, NW>), dim3(g), dim3(NW * 64), 0, s, a);
+        hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, false, NW, B16>), dim3(g), dim3(NW * 64), 0, s, a);
     }
     dbg_timing_end(s);
     return hipGetLastError();
