@@ -39,6 +39,33 @@ struct alignas(16) SplitXchg {
     float part[kNW][2 * D][kRows];   // layer-4 partial sums of every wave
 };
 
+// Forward solve: the hidden layers run on the bf16 matrix pipe with three-piece operands (cnf_device.h, field_fwd_b16).
+// A wave splits its OWN 4 values per stream before publishing them: per (stream, piece) it writes 4 bf16 = 8 bytes, laid
+// out so that the 16 bytes a lane reads back for k-step ks are the pieces of tiles 2ks and 2ks+1 -- the B operand of
+// v_mfma_f32_16x16x32_bf16 as it is.
+template <int D>
+struct alignas(16) SplitXchgB16 {
+    uint32_t xb16[2][kNSMaxOf<D>][3][2][64][4];   // [buffer][stream][piece][k-step][lane][tile & 1][2]
+    float part[kNW][2 * D][kRows];               // layer-4 partial sums of every wave
+};
+// this wave's weight operands of both hidden layers, held in registers for the whole solve: [layer][piece][k-step]
+struct SplitWeightsB16 {
+    bf16x8 a[2][3][2];
+    template <int D>
+    __device__ __forceinline__ void load(const NetLds<D>& n, int wave, int lane) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint32_t pc[8][3];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) split3_bf16(n.wimg[l][wave * 4 + 2 * ks + (k >> 2)][lane][k & 3], pc[k]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[l][p][ks] = mfma_b16_operand(pc, p);
+            }
+    }
+};
+
 template <class WS, int D>
 __device__ __forceinline__ void gates_into(const NetLds<D>& n, WS& ws, int lane, float t) {
 #pragma unroll
@@ -76,9 +103,9 @@ struct Prof {
 
 // ---- forward dynamics, feature-split over the 4 waves ---------------------------------------------------
 template <int D, bool HUTCH, class WS>
-__device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, SplitXchg<D>& xc, int lane, int wave, float t,
-                                                const float (&z)[D], const float (&e)[D], float (&f)[D], float& div,
-                                                Prof& pr) {
+__device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, const SplitWeightsB16& wb, WS& ws, SplitXchgB16<D>& xc,
+                                                int lane, int wave, float t, const float (&z)[D], const float (&e)[D],
+                                                float (&f)[D], float& div, Prof& pr) {
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     const int q = lane >> 4, j = lane & 15;
@@ -114,22 +141,44 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, WS& ws, Spli
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
+        for (int s = 0; s < NS; ++s) {
+            uint32_t pc[4][3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split3_bf16(act[s][r], pc[r]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                uint2 v;
+                v.x = (pc[0][p] >> 16) | pc[1][p];
+                v.y = (pc[2][p] >> 16) | pc[3][p];
+                *reinterpret_cast<uint2*>(&xc.xb16[l][s][p][wave >> 1][lane][2 * (wave & 1)]) = v;
+            }
+        }
         __syncthreads();
         pr.mark(3 + 3 * l);
         f32x4 acc[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int Ti = 0; Ti < 4; ++Ti) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&n.wimg[l][wave * 4 + Ti][lane][0]);
-            f32x4 in[NS];
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 b[NS][3];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int p = 0; p < 3; ++p)
+                    b[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xc.xb16[l][s][p][ks][lane][0]));
+            // six piece products, smallest first; consecutive MFMAs go to different accumulators
 #pragma unroll
-                for (int s = 0; s < NS; ++s) acc[s] = mfma16(a[r], in[s][r], acc[s]);
+            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][2], acc[s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][2][ks], b[s][0], acc[s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][1][ks], b[s][1], acc[s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][1], acc[s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][1][ks], b[s][0], acc[s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][0], acc[s]);
         }
         pr.mark(4 + 3 * l);
         const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
@@ -184,13 +233,15 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
     constexpr int C = D + 1;
     __shared__ NetLds<D> net;
     __shared__ SplitWaveLds<C> wl[kNW];
-    __shared__ SplitXchg<D> xc;
+    __shared__ SplitXchgB16<D> xc;
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
     stage_net(net, a.params, tid);
     zero_slopes(wl, kNW, tid);
     __syncthreads();
+    SplitWeightsB16 wb;
+    wb.load(net, w, lane);
     const long row = (long)blockIdx.x * kRows + j;
     const bool counted = row < a.rows && lane < 16 && w == 0;   // every wave carries the same 16 rows: count them once
     const long rr = row < a.rows ? row : a.rows - 1;
@@ -230,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
 #pragma unroll
         for (int m = 0; m < D; ++m) zz[m] = yi[m];
         pr.mark(0);
-        field_fwd_split<D, HUTCH>(net, ws, xc, lane, w, sgn * ti, zz, ee, f, div, pr);
+        field_fwd_split<D, HUTCH>(net, wb, ws, xc, lane, w, sgn * ti, zz, ee, f, div, pr);
         #pragma unroll
         for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
         div -= res * (float)D;
