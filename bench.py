@@ -244,7 +244,8 @@ def measure_roofline(ctx):
     flops = args.batch * st.nfe * 3 * F_EVAL_D2
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None   # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/): not measurable in-process
-    tpath = os.path.join(ROOT, "profiles", "r01f_bwd_traffic.json")
+    import glob
+    tpath = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bwd_traffic.json"))) or [""])[-1]   # the latest round's passes
     if os.path.exists(tpath) and args.batch == 2048:
         with open(tpath) as fh:
             traffic = json.load(fh)["hbm_bytes_per_launch"]

@@ -10,7 +10,9 @@
 //   * the weights are the A operand.  They are staged once per workgroup into LDS in operand order
 //     ("images": one ds_read_b128 per lane yields the A operands of four consecutive MFMAs);
 //   * f32-input MFMA is an exact k-ordered fmaf chain (cdna_hip_programming.md section 3), so the
-//     result is an ordinary fp32 matmul -- no reduced precision anywhere.
+//     result is an ordinary fp32 matmul.  The forward throughput kernels run the hidden layers on the bf16 pipe
+//     instead, with every fp32 operand split in three bf16 pieces (all 24 bits) and fp32 sums (field_fwd_b16
+//     below): no reduced precision anywhere either way.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
