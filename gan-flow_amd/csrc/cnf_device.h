@@ -315,8 +315,8 @@ __device__ __forceinline__ void field_fwd(const NetLds<D>& n, WaveLds<D>& ws, in
 // Throughput evaluation (tile-local dopri5, d <= 2).  On gfx950 the fp32 MFMA occupies the vector ALU for its whole
 // duration (tools/mfma_valu_overlap.hip); v_mfma_f32_16x16x32_bf16 runs beside it and does 8x the FLOP per clock.  Every
 // fp32 operand is written as hi + mid + lo, three TRUNCATED bf16 pieces (24 significant bits, every subtraction exact);
-// of the nine piece products the six of weight >= 2^-16 are kept (hh, hm, mh, hl, mm, lh: the dropped ones are below
-// 2^-24 of the product) and summed in fp32 by the matrix core, smallest first.  Measured on one 64 -> 64 layer against
+// of the nine piece products the six of weight >= 2^-16 are kept (hh, hm, mh, hl, mm, lh: the dropped ones amount to
+// 4e-8 of the product on average, < 2^-21 at worst) and summed in fp32 by the matrix core, smallest first.  Measured on one 64 -> 64 layer against
 // float64 (tools/bf16_split_layer.hip): rms error 6.3e-8 of the rms value -- the k-ordered fp32 fmaf chain of
 // v_mfma_f32_16x16x4_f32 has 1.5e-7 -- in 993 instead of 1 649 clocks per wave, split included.
 // The C/D register layout of a layer's output is a valid B operand of the 16x16x32 instruction as well: lane (q, j)

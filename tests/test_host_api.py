@@ -299,3 +299,34 @@ def test_one_library_per_nonlinearity():
         ODEnet((64, 64, 64), (2,), nonlinearity="swish")
     with pytest.raises(_native.CnfError):
         _native.net_desc(2, 64, 3, False, act="relu")
+
+
+def test_three_piece_bf16_split_keeps_every_bit():
+    """The arithmetic behind field_fwd_b16 / field_fwd_split (csrc/cnf_device.h, split3_bf16), restated in numpy: an fp32
+    value is the exact sum of three truncated bf16 pieces, and the six piece products the kernels keep differ from the
+    exact product by less than 2^-21 of it at worst and 2^-24 of it on average (what the three dropped ones amount to).  (Magnitudes whose third piece
+    would be denormal, below ~2^-110, lose bits there: 17 orders of magnitude under anything the flow produces.)"""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(20000) * np.exp(rng.uniform(-20, 20, 20000)), [0.0, -0.0, 1.0, -1.5, 1.0e-30, 1.0e38]]).astype(np.float32)
+
+    def split3(v):
+        p0 = (v.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        r1 = (v - p0).astype(np.float32)
+        p1 = (r1.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        r2 = (r1 - p1).astype(np.float32)
+        p2 = (r2.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        return p0, p1, p2, (r2 - p2).astype(np.float32)
+
+    p0, p1, p2, rest = split3(x)
+    assert np.all(rest == 0)                                      # nothing is left after three pieces
+    assert np.array_equal((p0.astype(np.float64) + p1 + p2).astype(np.float32), x)
+    for p in (p0, p1, p2):                                        # each piece is a bf16: lower 16 bits clear
+        assert np.all(p.view(np.uint32) & np.uint32(0xFFFF) == 0)
+    y = rng.permutation(x[:20000])
+    a, b = split3(x[:20000]), split3(y)
+    kept = sum(a[i].astype(np.float64) * b[j] for i, j in ((0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)))
+    exact = x[:20000].astype(np.float64) * y
+    ok = np.isfinite(exact) & (np.abs(exact) > 1e-30) & (np.abs(exact) < 1e30)
+    rel = np.abs(kept - exact)[ok] / np.abs(exact)[ok]
+    print("kept six of nine piece products: max rel err %.3e mean %.3e" % (rel.max(), rel.mean()))
+    assert rel.max() < 2.0 ** -21 and rel.mean() < 2.0 ** -24
