@@ -64,6 +64,73 @@ __device__ inline void stage_wimgT(float* img, const float* __restrict__ p, int 
     }
 }
 
+// this wave's weight operands of both hidden layers, held in registers for the whole solve: [layer][piece][k-step]
+struct SplitWeightsB16 {
+    bf16x8 a[2][3][2];
+    template <int D>
+    __device__ __forceinline__ void load(const NetLds<D>& n, int wave, int lane) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint32_t pc[8][3];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) split3_bf16(n.wimg[l][wave * 4 + 2 * ks + (k >> 2)][lane][k & 3], pc[k]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[l][p][ks] = mfma_b16_operand(pc, p);
+            }
+    }
+};
+
+// A wave publishes its own 4 values per stream as bf16 pieces: per (stream, piece) 4 bf16 = 8 bytes, placed so that the 16
+// bytes a lane reads back for k-step ks are the pieces of tiles 2ks and 2ks+1 -- the B operand of
+// v_mfma_f32_16x16x32_bf16 as it is.  xb16: one buffer, [stream][piece][k-step][lane][tile & 1][2].
+template <int NS>
+__device__ __forceinline__ void publish_b16(uint32_t (*xb16)[3][2][64][4], const f32x4 (&act)[NS], int wave, int lane) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        uint32_t pc[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) split3_bf16(act[s][r], pc[r]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            uint2 v;
+            v.x = (pc[0][p] >> 16) | pc[1][p];
+            v.y = (pc[2][p] >> 16) | pc[3][p];
+            *reinterpret_cast<uint2*>(&xb16[s][p][wave >> 1][lane][2 * (wave & 1)]) = v;
+        }
+    }
+}
+// this wave's 16 output features of hidden layer l for NS streams: six piece products per k-step, smallest first,
+// consecutive MFMAs to different accumulators
+template <int NS>
+__device__ __forceinline__ void hidden_b16(const uint32_t (*xb16)[3][2][64][4], const SplitWeightsB16& wb, int l, int lane,
+                                           f32x4 (&acc)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 b[NS][3];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xb16[s][p][ks][lane][0]));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][2], acc[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][2][ks], b[s][0], acc[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][1][ks], b[s][1], acc[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][1], acc[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][1][ks], b[s][0], acc[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][0], acc[s]);
+    }
+}
+
 // sum of the workgroups' gradient slabs in a fixed order (kernel in cnf_split.hip)
 hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s, int split_at = 0);
 // slab sum (as launch_reduce_slab) + Adam update of the P parameters in one kernel; grad_out may be null

@@ -48,24 +48,6 @@ struct alignas(16) SplitXchgB16 {
     uint32_t xb16[2][kNSMaxOf<D>][3][2][64][4];   // [buffer][stream][piece][k-step][lane][tile & 1][2]
     float part[kNW][2 * D][kRows];               // layer-4 partial sums of every wave
 };
-// this wave's weight operands of both hidden layers, held in registers for the whole solve: [layer][piece][k-step]
-struct SplitWeightsB16 {
-    bf16x8 a[2][3][2];
-    template <int D>
-    __device__ __forceinline__ void load(const NetLds<D>& n, int wave, int lane) {
-#pragma unroll
-        for (int l = 0; l < 2; ++l)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint32_t pc[8][3];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) split3_bf16(n.wimg[l][wave * 4 + 2 * ks + (k >> 2)][lane][k & 3], pc[k]);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) a[l][p][ks] = mfma_b16_operand(pc, p);
-            }
-    }
-};
-
 template <class WS, int D>
 __device__ __forceinline__ void gates_into(const NetLds<D>& n, WS& ws, int lane, float t) {
 #pragma unroll
@@ -140,46 +122,11 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, const SplitW
     pr.mark(2);
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            uint32_t pc[4][3];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) split3_bf16(act[s][r], pc[r]);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                uint2 v;
-                v.x = (pc[0][p] >> 16) | pc[1][p];
-                v.y = (pc[2][p] >> 16) | pc[3][p];
-                *reinterpret_cast<uint2*>(&xc.xb16[l][s][p][wave >> 1][lane][2 * (wave & 1)]) = v;
-            }
-        }
+        publish_b16<NS>(xc.xb16[l], act, wave, lane);
         __syncthreads();
         pr.mark(3 + 3 * l);
         f32x4 acc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 b[NS][3];
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    b[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xc.xb16[l][s][p][ks][lane][0]));
-            // six piece products, smallest first; consecutive MFMAs go to different accumulators
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][2], acc[s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][2][ks], b[s][0], acc[s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][1][ks], b[s][1], acc[s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][1], acc[s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][1][ks], b[s][0], acc[s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] = mfma_b16(wb.a[l][0][ks], b[s][0], acc[s]);
-        }
+        hidden_b16<NS>(xc.xb16[l], wb, l, lane, acc);
         pr.mark(4 + 3 * l);
         const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
         const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);

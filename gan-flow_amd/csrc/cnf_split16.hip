@@ -31,6 +31,12 @@ struct alignas(16) Xchg16 {
     float part[kNW][2][64][4];  // layer-4 partial results of every wave: [wave][stream][lane][r]
 };
 
+// forward solve: hidden activations travel as bf16 pieces (cnf_split.h, publish_b16 / hidden_b16)
+struct alignas(16) Xchg16F {
+    uint32_t xb16[2][2][3][2][64][4];   // [buffer][stream][piece][k-step][lane][tile & 1][2]
+    float part[kNW][2][64][4];
+};
+
 __device__ __forceinline__ f32x4 sum4v(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) { return ((a + b) + c) + d; }
 
 template <class NET, class WS>
@@ -51,9 +57,9 @@ __device__ __forceinline__ void gates16(const NET& n, WS& ws, int lane, float t)
 
 // f(t, z) and e^T (df/dz) e for the 16 rows of the workgroup; z4 / e4 / f4: this lane's 4 components.
 // w1img[r] = W1[16 wave + (lane & 15)][4 (lane >> 4) + r],  w4img[r] = W4[lane & 15][16 wave + 4 (lane >> 4) + r].
-__device__ __forceinline__ void field_fwd16(const NetLds<kD>& n, Wave16Lds& ws, Xchg16& xc, const f32x4& w1img,
-                                            const f32x4& w4img, int lane, int wave, float t, const f32x4& z4,
-                                            const f32x4& e4, f32x4& f4, float& div) {
+__device__ __forceinline__ void field_fwd16(const NetLds<kD>& n, const SplitWeightsB16& wb, Wave16Lds& ws, Xchg16F& xc,
+                                            const f32x4& w1img, const f32x4& w4img, int lane, int wave, float t,
+                                            const f32x4& z4, const f32x4& e4, f32x4& f4, float& div) {
     const int q = lane >> 4;
     const int fo = 16 * wave + 4 * q;
     gates16(n, ws, lane, t);
@@ -76,21 +82,10 @@ __device__ __forceinline__ void field_fwd16(const NetLds<kD>& n, Wave16Lds& ws, 
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
+        publish_b16<2>(xc.xb16[l], act, wave, lane);
         __syncthreads();
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int Ti = 0; Ti < 4; ++Ti) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&n.wimg[l][wave * 4 + Ti][lane][0]);
-            f32x4 in[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) acc[s] = mfma16(a[r], in[s][r], acc[s]);
-        }
+        f32x4 acc[2];
+        hidden_b16<2>(xc.xb16[l], wb, l, lane, acc);
         const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
         const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
 #pragma unroll
@@ -132,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLds<kD> net;
     __shared__ Wave16Lds wl[kNW];
-    __shared__ Xchg16 xc;
+    __shared__ Xchg16F xc;
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
     if (tid == 0) red.status = 0;
@@ -142,6 +137,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
     const f32x4 w1img = *reinterpret_cast<const f32x4*>(a.params + L.w(0) + (16 * w + j) * kD + 4 * q);
     const f32x4 w4img = *reinterpret_cast<const f32x4*>(a.params + L.w(3) + j * kH + 16 * w + 4 * q);
     __syncthreads();
+    SplitWeightsB16 wb;
+    wb.load(net, w, lane);
     const long row = (long)blockIdx.x * kRows + j;
     // every wave carries the same 16 rows: wave 0 reports them, every quarter its own 4 dimensions, quarter 0 logp
     const bool cz = row < a.rows && w == 0;
@@ -182,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
         bool restart = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) z4[r] = yi[r];
-        field_fwd16(net, ws, xc, w1img, w4img, lane, w, sgn * ti, z4, e4, f4, div);
+        field_fwd16(net, wb, ws, xc, w1img, w4img, lane, w, sgn * ti, z4, e4, f4, div);
 #pragma unroll
         for (int r = 0; r < 4; ++r) f4[r] = fmaf(-res, z4[r], f4[r]);   // residual dynamics f(z) - z (res = 0 or 1)
         div -= res * (float)kD;
