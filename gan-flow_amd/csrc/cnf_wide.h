@@ -30,7 +30,17 @@ struct alignas(16) WideWaveLds {
 template <int D, int NS, int NB = 2>
 struct alignas(16) WideXchg {
     static constexpr int kBuffers = NB;
+    static constexpr bool kB16 = false;
     float xb[NB][NS][kWT][64][4];
+    float part[kNW][2 * D][kRows];
+};
+// Forward dopri5 solves: activations travel as bf16 pieces for v_mfma_f32_16x16x32_bf16 (cnf_device.h, field_fwd_b16;
+// layout as SplitXchgB16, 8 k-steps of two input tiles each).  1.5x the bytes of the fp32 buffer: one buffer only.
+template <int D, int NS, int NB = 1>
+struct alignas(16) WideXchgB16 {
+    static constexpr int kBuffers = NB;
+    static constexpr bool kB16 = true;
+    uint32_t xb16[NB][NS][3][kWT / 2][64][4];   // [buffer][stream][piece][k-step][lane][tile & 1][2]
     float part[kNW][2 * D][kRows];
 };
 

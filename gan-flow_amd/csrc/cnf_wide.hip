@@ -12,13 +12,21 @@
 // against ~25k cycles of MFMA work per wave, i.e. ~10 B/clk of L2 bandwidth: the layer is MFMA-bound.
 // Forward path only (field evaluation, dopri5 with batch-global or tile-local control, rk4); the adjoint at this
 // width needs 2 x 256 x 256 gradient accumulators per workgroup, which do not fit in registers: not built yet.
+#include <type_traits>
+
 #include "cnf_wide.h"
 
 #ifndef CNF_WIDE_PF
 #define CNF_WIDE_PF 1
 #endif
+// dopri5 forward solves at this width run their hidden layers on the bf16 matrix pipe with split operands (0: fp32 MFMAs)
+#ifndef CNF_WIDE_BF16
+#define CNF_WIDE_BF16 1
+#endif
 
 namespace cnf {
+
+constexpr bool kWideB16 = CNF_WIDE_BF16 != 0;
 
 // ---- forward dynamics -----------------------------------------------------------------------------------------
 template <int D, bool HUTCH, class WS, class XC>
@@ -78,12 +86,81 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
         constexpr int NB = XC::kBuffers;
         const int lb = l % NB;
         if (NB == 1 && l == 1) __syncthreads();   // every wave is past its reads of layer 2's input
+        // row 64 wave + 16 T + j of W, columns 16 Ti + 4 q .. + 3
+        const float* wrow = params + make_layout(D, kWH).w(1 + l) + (size_t)(kWF * wave + j) * kWH + 4 * q;
+        f32x4 acc[kWTW][NS];
+        if constexpr (XC::kB16) {
+            // bf16 pipe, three-piece operands (cnf_device.h): activations are split by the wave that owns them and published
+            // as pieces; the weight blocks of k-step ks (input tiles 2ks, 2ks+1) arrive as fp32 from L2, one k-step ahead,
+            // and are split on the way into the A operand -- vector work that runs beside the matrix pipe.
+#pragma unroll
+            for (int T = 0; T < kWTW; ++T) {
+                const int tg = kWTW * wave + T;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    uint32_t pc[4][3];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) split3_bf16(act[T][s][r], pc[r]);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        uint2 v;
+                        v.x = (pc[0][p] >> 16) | pc[1][p];
+                        v.y = (pc[2][p] >> 16) | pc[3][p];
+                        *reinterpret_cast<uint2*>(&xc.xb16[lb][s][p][tg >> 1][lane][2 * (tg & 1)]) = v;
+                    }
+                }
+            }
+            f32x4 wb[2][2][kWTW];   // [ring slot][tile of the pair][output tile]
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int T = 0; T < kWTW; ++T) wb[0][h][T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * h);
+            __syncthreads();
+#pragma unroll
+            for (int T = 0; T < kWTW; ++T)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[T][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int ks = 0; ks < kWT / 2; ++ks) {
+                const int kn = ks + 1 < kWT / 2 ? ks + 1 : kWT / 2 - 1;   // past the end: a redundant load instead of a branch
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int T = 0; T < kWTW; ++T)
+                        wb[(ks + 1) & 1][h][T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * (2 * kn + h));
+                bf16x8 b[NS][3];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        b[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xc.xb16[lb][s][p][ks][lane][0]));
+#pragma unroll
+                for (int T = 0; T < kWTW; ++T) {
+                    uint32_t pc[8][3];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) split3_bf16(wb[ks & 1][k >> 2][T][k & 3], pc[k]);
+                    bf16x8 aw[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) aw[p] = mfma_b16_operand(pc, p);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][2], acc[T][s]);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[2], b[s][0], acc[T][s]);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[1], b[s][1], acc[T][s]);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][1], acc[T][s]);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[1], b[s][0], acc[T][s]);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][0], acc[T][s]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int T = 0; T < kWTW; ++T)
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[lb][s][kWTW * wave + T][lane][0]) = act[T][s];
-        // row 64 wave + 16 T + j of W, columns 16 Ti + 4 q .. + 3
-        const float* wrow = params + make_layout(D, kWH).w(1 + l) + (size_t)(kWF * wave + j) * kWH + 4 * q;
         // ring of kPF + 1 register buffers: the blocks of input tiles Ti + 1 .. Ti + kPF are in flight while tile Ti
         // feeds the matrix pipe (one tile = 48 MFMAs ~ 1.5k cycles at NS = 3; an L2 round trip is of that order)
         constexpr int kPF = CNF_WIDE_PF, kRing = kPF + 1;
@@ -93,7 +170,6 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
 #pragma unroll
             for (int T = 0; T < kWTW; ++T) wbuf[p][T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * p);   // issued before the barrier
         __syncthreads();
-        f32x4 acc[kWTW][NS];
 #pragma unroll
         for (int T = 0; T < kWTW; ++T)
 #pragma unroll
@@ -115,6 +191,7 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
 #pragma unroll
                     for (int s = 0; s < NS; ++s) acc[T][s] = mfma16(wbuf[Ti % kRing][T][r], in[s][r], acc[T][s]);
         }
+        }   // fp32 MFMA path
 #pragma unroll
         for (int T = 0; T < kWTW; ++T) {
             const int lo = 16 * T + 4 * q;
@@ -288,14 +365,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 // Tile-local: two workgroups per CU (single exchange buffer, registers capped at 256), so that one workgroup's
 // barriers, tanh and weight-stream latency are covered by the other's MFMAs.
 template <int D, bool HUTCH, bool GLOBAL>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GLOBAL ? 1 : 2, GLOBAL ? 8 : 2)))
-void wide_dopri5_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GLOBAL || kWideB16 ? 1 : 2, GLOBAL || kWideB16 ? 8 : 2)))
+void wide_dopri5_kernel(SolveArgs a) {   // (bf16 path: no register cap -- its piece buffers make d = 2 one workgroup per CU anyway, and no spills)
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = D + 1;
     __shared__ WideNetLds<D> net;
     __shared__ WideWaveLds<C> wl[kNW];
-    __shared__ WideXchg<D, NS, GLOBAL ? 2 : 1> xc;
+    __shared__ typename std::conditional<kWideB16, WideXchgB16<D, NS, 1>, WideXchg<D, NS, GLOBAL ? 2 : 1>>::type xc;
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
