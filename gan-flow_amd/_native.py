@@ -42,7 +42,7 @@ STATUS_MESSAGES = {
 }
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
            "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
-           "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation")
+           "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation", "cnf_debug_eval_field_b16")
 
 
 def library_path(act="tanh"):
@@ -73,6 +73,8 @@ def load_library(act="tanh"):
     lib.cnf_last_error.argtypes = []
     lib.cnf_eval_field.restype = ctypes.c_int
     lib.cnf_eval_field.argtypes = [ND, P, F, P, P, I64, P, P, VP]
+    lib.cnf_debug_eval_field_b16.restype = ctypes.c_int
+    lib.cnf_debug_eval_field_b16.argtypes = [ND, P, F, P, P, I64, P, P, VP]
     lib.cnf_solve_fwd.restype = ctypes.c_int
     lib.cnf_solve_fwd.argtypes = [ND, P, P, P, P, I64, F, F, SO, P, P, VP, SZ, P, VP]
     lib.cnf_eval_aug.restype = ctypes.c_int
@@ -215,8 +217,9 @@ def _stats_block(stats, device):
     return stats
 
 
-def eval_field(net, params, t, z, e=None):
-    """(f, -div) = ODEfunc.forward(t, (z, .)) for a (rows, dim) batch."""
+def eval_field(net, params, t, z, e=None, b16=False):
+    """(f, -div) = ODEfunc.forward(t, (z, .)) for a (rows, dim) batch.  b16: computed the way the forward dopri5 solves at
+    hidden width 64, dim <= 2 compute it (hidden layers on the bf16 pipe with three-piece operands; diagnostics)."""
     lib = _lib_for(net)
     z = _dev(z, "z")
     rows = z.shape[0]
@@ -225,8 +228,8 @@ def eval_field(net, params, t, z, e=None):
     f = torch.empty_like(z)
     nd = torch.empty(rows, 1, dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
-        _check(lib.cnf_eval_field(ctypes.byref(net), _ptr(params), float(t), _ptr(z), _ptr(e), rows, _ptr(f), _ptr(nd),
-                                  _stream()), lib)
+        fn = lib.cnf_debug_eval_field_b16 if b16 else lib.cnf_eval_field
+        _check(fn(ctypes.byref(net), _ptr(params), float(t), _ptr(z), _ptr(e), rows, _ptr(f), _ptr(nd), _stream()), lib)
     return f, nd
 
 

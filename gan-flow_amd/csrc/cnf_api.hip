@@ -169,6 +169,20 @@ int cnf_eval_field(const CnfNetDesc* net, const float* params, float t, const fl
     return 0;
 }
 
+int cnf_debug_eval_field_b16(const CnfNetDesc* net, const float* params, float t, const float* z, const float* e,
+                             int64_t rows, float* f_out, float* neg_div_out, void* stream) {
+    if (check_net(net)) return 1;
+    if (!params || !z || !f_out || !neg_div_out) return fail("cnf_debug_eval_field_b16: NULL pointer");
+    if (rows <= 0) return fail("cnf_debug_eval_field_b16: rows must be positive (got %ld)", (long)rows);
+    if (is_wide(net) || net->dim > 2) return fail("cnf_debug_eval_field_b16: hidden width 64 and dim <= 2 only");
+    const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
+    if (hutch && !e) return fail("cnf_debug_eval_field_b16: Hutchinson divergence needs the probe e");
+    hipError_t err = cnf::launch_field(net->dim, hutch, params, t, z, e, rows, f_out, neg_div_out, (hipStream_t)stream,
+                                       is_residual(net) ? 1.f : 0.f, true);
+    if (err != hipSuccess) return fail("cnf_debug_eval_field_b16: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
 static int fill_common(const char* who, const CnfNetDesc* net, const float* params, int64_t rows, float t0, float t1,
                        const CnfSolverOpts* opts, void* workspace, size_t workspace_bytes, CnfStats* stats,
                        cnf::SolveArgs& a, bool& global) {

@@ -13,23 +13,19 @@ namespace cnf {
 // ------------------------------------------------------------------------------------------------
 // single evaluation (ODEfunc.forward)
 // ------------------------------------------------------------------------------------------------
-template <int D, bool HUTCH>
+template <int D, bool HUTCH, bool B16 = false>   // B16: hidden layers on the bf16 pipe (cnf_debug_eval_field_b16)
 __global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict__ params, float t,
                                                          const float* __restrict__ z, const float* __restrict__ e,
                                                          long rows, float* __restrict__ f_out,
                                                          float* __restrict__ neg_div_out, float res) {
-#if defined(CNF_DBG_FIELD_B16)   // debugging aid: cnf_eval_field through the bf16-split layers (tools/build_variants.sh)
-    __shared__ NetLdsB16<D> net;
-#else
-    __shared__ NetLds<D> net;
-#endif
+    __shared__ typename std::conditional<B16, NetLdsB16<D>, NetLds<D>>::type net;
     __shared__ WaveLds<D> wl[kNW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
-#if defined(CNF_DBG_FIELD_B16)
-    stage_net_b16(net, params, tid, kThreads);
-#else
-    stage_net(net, params, tid);
-#endif
+    if constexpr (B16) {
+        stage_net_b16(net, params, tid, kThreads);
+    } else {
+        stage_net(net, params, tid);
+    }
     __syncthreads();
     const long base = ((long)blockIdx.x * kNW + w) * kRows;
     if (base >= rows) return;
@@ -41,11 +37,11 @@ __global__ __launch_bounds__(kThreads) void field_kernel(const float* __restrict
         zz[m] = z[rr * D + m];
         ee[m] = HUTCH ? e[rr * D + m] : 0.f;
     }
-#if defined(CNF_DBG_FIELD_B16)
-    field_fwd_b16<D, HUTCH>(net, wl[w], lane, t, zz, ee, f, div);
-#else
-    field_fwd<D, HUTCH>(net, wl[w], lane, t, zz, ee, f, div);
-#endif
+    if constexpr (B16) {
+        field_fwd_b16<D, HUTCH>(net, wl[w], lane, t, zz, ee, f, div);
+    } else {
+        field_fwd<D, HUTCH>(net, wl[w], lane, t, zz, ee, f, div);
+    }
     #pragma unroll
     for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
     div -= res * (float)D;
@@ -419,20 +415,26 @@ __global__ __launch_bounds__(NW * 64)
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-template <int D, bool HUTCH>
+template <int D, bool HUTCH, bool B16>
 static hipError_t launch_field_t(const float* params, float t, const float* z, const float* e, long rows,
                                  float* f_out, float* nd_out, hipStream_t s, float res) {
     const int grid = (int)((rows + kRowsPerWG - 1) / kRowsPerWG);
-    hipLaunchKernelGGL((field_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, params, t, z, e, rows, f_out, nd_out, res);
+    hipLaunchKernelGGL((field_kernel<D, HUTCH, B16>), dim3(grid), dim3(kThreads), 0, s, params, t, z, e, rows, f_out, nd_out, res);
     return hipGetLastError();
 }
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
-                        float* f_out, float* nd_out, hipStream_t s, float res) {
-    if (D == 1 && !hutch) return launch_field_t<1, false>(params, t, z, e, rows, f_out, nd_out, s, res);
-    if (D == 2 && !hutch) return launch_field_t<2, false>(params, t, z, e, rows, f_out, nd_out, s, res);
-    if (D == 2 && hutch) return launch_field_t<2, true>(params, t, z, e, rows, f_out, nd_out, s, res);
-    if (D == 16 && hutch) return launch_field_t<16, true>(params, t, z, e, rows, f_out, nd_out, s, res);
+                        float* f_out, float* nd_out, hipStream_t s, float res, bool b16) {
+    if (b16) {   // the arithmetic of the tile-local / split forward solves (d <= 2)
+        if (D == 1 && !hutch) return launch_field_t<1, false, true>(params, t, z, e, rows, f_out, nd_out, s, res);
+        if (D == 2 && !hutch) return launch_field_t<2, false, true>(params, t, z, e, rows, f_out, nd_out, s, res);
+        if (D == 2 && hutch) return launch_field_t<2, true, true>(params, t, z, e, rows, f_out, nd_out, s, res);
+        return hipErrorInvalidValue;
+    }
+    if (D == 1 && !hutch) return launch_field_t<1, false, false>(params, t, z, e, rows, f_out, nd_out, s, res);
+    if (D == 2 && !hutch) return launch_field_t<2, false, false>(params, t, z, e, rows, f_out, nd_out, s, res);
+    if (D == 2 && hutch) return launch_field_t<2, true, false>(params, t, z, e, rows, f_out, nd_out, s, res);
+    if (D == 16 && hutch) return launch_field_t<16, true, false>(params, t, z, e, rows, f_out, nd_out, s, res);
     return hipErrorInvalidValue;
 }
 

@@ -36,7 +36,7 @@ struct SolveArgs {
 };
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
-                        float* f_out, float* nd_out, hipStream_t s, float res = 0.f);
+                        float* f_out, float* nd_out, hipStream_t s, float res = 0.f, bool b16 = false);
 hipError_t launch_solve_fwd(int D, bool hutch, const SolveArgs& a, int solver, bool global, hipStream_t s);
 // d = 16, Hutchinson, rows <= 4096, x / e / z_out / params 16-byte aligned (cnf_split16.hip)
 hipError_t launch_split16_fwd(const SolveArgs& a, hipStream_t s);

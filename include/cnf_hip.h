@@ -188,6 +188,13 @@ int cnf_solve_bwd_train(const CnfNetDesc *net, float *params, const float *z1, c
  * depends on it.  scratch_word: one uint32 of device memory (never written in practice).                    */
 int cnf_debug_fill_lds(uint32_t pattern, uint32_t *scratch_word, void *stream);
 
+/* Diagnostics (no counterpart in the reference): cnf_eval_field computed the way the forward dopri5 solves at hidden
+ * width 64 and dim <= 2 compute it -- hidden layers on the bf16 matrix pipe, every fp32 operand split into three bf16
+ * pieces, fp32 sums -- so that tests can hold that arithmetic against the oracle and against
+ * float64 one evaluation at a time.  Same arguments and conventions as cnf_eval_field.                       */
+int cnf_debug_eval_field_b16(const CnfNetDesc *net, const float *params, float t, const float *z, const float *e,
+                             int64_t rows, float *f_out, float *neg_div_out, void *stream);
+
 /* Diagnostics (no counterpart in the reference): while enabled, cnf_solve_fwd / cnf_solve_bwd record a HIP event on
  * the launch stream immediately before and after their solve kernel (not the memsets, not the slab reduction);
  * cnf_debug_last_kernel_ms waits for the second event and returns the elapsed time of the most recent solve kernel.

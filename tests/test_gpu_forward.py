@@ -7,6 +7,8 @@ Tolerances (fp32 path):
     (controller decisions are taken on batch means, so summation-order noise cannot flip them except at
     exact ties; a test that flips would show up as an NFE mismatch).
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -88,6 +90,40 @@ def _solve_pair(m, x, reverse, solver, device_model=None, step_size=None, tile_r
     st = nat.Stats(st)
     st.raise_for_status()
     return (z_ref[1], l_ref[1], stats), (z.cpu(), l.cpu(), st)
+
+
+@pytest.mark.parametrize("which", ["unimodal", "multimodal", "random_d2", "random_d2_hutch"])
+def test_field_b16_arithmetic_matches_fp32_and_float64(which):
+    """The hidden-layer arithmetic of the forward dopri5 solves (bf16 matrix pipe, every fp32 operand split into three
+    bf16 pieces, fp32 sums: cnf_debug_eval_field_b16) one evaluation at a time: within 1e-5 of the oracle like
+    cnf_eval_field, and no further from the float64 evaluation of the same weights than the fp32-MFMA path is (x1.5)."""
+    nat = _native()
+    g = torch.Generator().manual_seed(17)
+    if which in ("unimodal", "multimodal"):
+        m, dim, hutch = oracle_fixture_model(which), 1, False
+        lo, hi = (4.5, 5.5) if which == "unimodal" else (7.0, 83.0)
+        x = torch.rand(1000, 1, generator=g) * (hi - lo) + lo
+    else:
+        hutch = which.endswith("hutch")
+        m, dim = oracle_random_model(2, seed=3, divergence_fn="approximate" if hutch else "brute_force", scale=2.0), 2
+        x = torch.randn(1000, 2, generator=g)
+    e = torch.randn(1000, dim, generator=g) if hutch else None
+    net, params = nat.net_desc(dim, 64, 3, hutch), _flat(m).to(DEV)
+    m64 = copy.deepcopy(m).double()
+    fn64 = m64.chain[0].odefunc.odefunc
+    for t in (0.0, 0.21, 0.5):
+        f32_, nd32 = nat.eval_field(net, params, t, x.to(DEV), None if e is None else e.to(DEV))
+        f16_, nd16 = nat.eval_field(net, params, t, x.to(DEV), None if e is None else e.to(DEV), b16=True)
+        fn64.before_odeint(e=None if e is None else e.double())
+        with torch.enable_grad():
+            xr = x.double().requires_grad_(True)
+            fr, ndr = fn64(torch.tensor(t, dtype=torch.float64), (xr, torch.zeros(1000, 1, dtype=torch.float64)))[:2]
+        fr, ndr = fr.detach(), ndr.detach().reshape(-1, 1)
+        sf, sd = fr.abs().max().item(), ndr.abs().max().item()
+        e32 = max((f32_.cpu().double() - fr).abs().max().item() / sf, (nd32.cpu().double() - ndr).abs().max().item() / sd)
+        e16 = max((f16_.cpu().double() - fr).abs().max().item() / sf, (nd16.cpu().double() - ndr).abs().max().item() / sd)
+        print("%s t=%.2f: max err / max |value| vs float64: fp32 MFMA %.2e, bf16 split %.2e" % (which, t, e32, e16))
+        assert e16 < 1e-5 and e16 <= 1.5 * e32 + 2e-7
 
 
 @pytest.mark.parametrize("which,reverse", [("unimodal", False), ("unimodal", True), ("multimodal", False), ("multimodal", True)])
@@ -238,7 +274,7 @@ def test_dopri5_tile_local_control_matches_oracle_per_tile(which):
     print("tile-local %s: nfe max hip %d oracle %d, row_evals hip %d oracle %d, max dz %.2e dlogp %.2e"
           % (which, st.nfe, nfe_max, st.row_evals, row_evals, dz, dl))
     # The tile-local kernel runs its hidden layers on the bf16 matrix pipe with three-piece operands (field_fwd_b16): as
-    # accurate as the fp32 chain (tools/dbg_field_b16.py: same distance from the float64 field) but rounded differently
+    # accurate as the fp32 chain (test_field_b16_arithmetic_matches_fp32_and_float64: same distance from the float64 field) but rounded differently
     # from the oracle's fp32 matmul, and a 16-row (or 6-row) mean decides each attempt -- borderline decisions flip in
     # some tiles.  The bar: attempt counts stay close; the MEAN error against the float64 tight-tolerance solution is
     # no larger than the fp32 oracle's (x2); the maximum over these 70 rows stays inside the error distribution that
