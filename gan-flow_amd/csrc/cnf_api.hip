@@ -65,6 +65,7 @@ int fail(const char* fmt, ...) {
 constexpr size_t kGranBytes = 2 * (size_t)cnf::kMaxWG * 4 * sizeof(unsigned long long) + 64;  // 16 KiB of granules + the ticket word
 
 constexpr int kWideH = 256;   // cnf_wide.hip
+constexpr size_t kWidePieceBytes = 786432;   // cnf_wide.h: bf16 pieces of the two hidden matrices (forward dopri5 solves)
 
 bool is_wide(const CnfNetDesc* n) { return n->hidden == kWideH; }
 bool is_residual(const CnfNetDesc* n) { return (n->divergence & CNF_DIV_RESIDUAL) != 0; }
@@ -141,9 +142,11 @@ int64_t cnf_param_count(const CnfNetDesc* net) {
 size_t cnf_workspace_bytes(const CnfNetDesc* net, int64_t rows) {
     if (!supported(net) || rows <= 0) return 0;
     if (is_wide(net)) {
-        // forward: granules only.  Adjoint (rows <= 4096): transposed matrices + 8 gradient slots per 16-row tile.
-        if (rows > (int64_t)cnf::kRows * cnf::kMaxWG) return kGranBytes;
-        return kGranBytes + cnf::wide_bwd_workspace_floats(net->dim, rows) * sizeof(float);
+        // forward: granules + the bf16 pieces of the two hidden matrices (768 KB, written per dopri5 launch).  Adjoint
+        // (rows <= 4096): transposed matrices + 8 gradient slots per 16-row tile in the same region (always larger).
+        if (rows > (int64_t)cnf::kRows * cnf::kMaxWG) return kGranBytes + kWidePieceBytes;
+        const size_t bwd = cnf::wide_bwd_workspace_floats(net->dim, rows) * sizeof(float);
+        return kGranBytes + (bwd > kWidePieceBytes ? bwd : kWidePieceBytes);
     }
     const size_t P = (size_t)cnf::make_layout(net->dim, net->hidden).total;
     return kGranBytes + align16((size_t)n_slabs(net, rows) * P * sizeof(float));

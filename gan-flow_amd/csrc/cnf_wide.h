@@ -8,6 +8,7 @@ constexpr int kWH = 256;                 // hidden width
 constexpr int kWT = kWH / 16;            // feature tiles per layer (16)
 constexpr int kWTW = kWT / kNW;          // output tiles per wave (4)
 constexpr int kWF = kWH / kNW;           // features per wave (64)
+constexpr size_t kWidePieceBytes = (size_t)2 * kWT * (kWT / 2) * 3 * 64 * 16;   // wide_split_weights_kernel's output (786 432)
 
 template <int D>
 struct alignas(16) WideNetLds {

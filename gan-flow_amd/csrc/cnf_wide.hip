@@ -32,7 +32,8 @@ constexpr bool kWideB16 = CNF_WIDE_BF16 != 0;
 template <int D, bool HUTCH, class WS, class XC>
 __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, XC& xc,
                                                const float* __restrict__ params, int lane, int wave, float t,
-                                               const float (&z)[D], const float (&e)[D], float (&f)[D], float& div) {
+                                               const float (&z)[D], const float (&e)[D], float (&f)[D], float& div,
+                                               const u32x4* __restrict__ wpieces = nullptr) {
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     const int q = lane >> 4, j = lane & 15;
@@ -91,8 +92,7 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
         f32x4 acc[kWTW][NS];
         if constexpr (XC::kB16) {
             // bf16 pipe, three-piece operands (cnf_device.h): activations are split by the wave that owns them and published
-            // as pieces; the weight blocks of k-step ks (input tiles 2ks, 2ks+1) arrive as fp32 from L2, one k-step ahead,
-            // and are split on the way into the A operand -- vector work that runs beside the matrix pipe.
+            // as pieces; the weight pieces of k-step ks (input tiles 2ks, 2ks+1) stream from L2 one k-step ahead.
 #pragma unroll
             for (int T = 0; T < kWTW; ++T) {
                 const int tg = kWTW * wave + T;
@@ -110,11 +110,14 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
                     }
                 }
             }
-            f32x4 wb[2][2][kWTW];   // [ring slot][tile of the pair][output tile]
+            // weight pieces of this wave's 4 output tiles, k-step ks: [layer][Tout][k-step][piece][lane] x 16 bytes, written
+            // once per launch by wide_split_weights_kernel; ring of two k-steps
+            const u32x4* wp = wpieces + ((size_t)(l * kWT + kWTW * wave) * (kWT / 2) * 3) * 64 + lane;
+            u32x4 wb[2][kWTW][3];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int T = 0; T < kWTW; ++T)
 #pragma unroll
-                for (int T = 0; T < kWTW; ++T) wb[0][h][T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * h);
+                for (int p = 0; p < 3; ++p) wb[0][T][p] = wp[((size_t)(T * (kWT / 2) + 0) * 3 + p) * 64];
             __syncthreads();
 #pragma unroll
             for (int T = 0; T < kWTW; ++T)
@@ -124,10 +127,9 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
             for (int ks = 0; ks < kWT / 2; ++ks) {
                 const int kn = ks + 1 < kWT / 2 ? ks + 1 : kWT / 2 - 1;   // past the end: a redundant load instead of a branch
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int T = 0; T < kWTW; ++T)
 #pragma unroll
-                    for (int T = 0; T < kWTW; ++T)
-                        wb[(ks + 1) & 1][h][T] = *reinterpret_cast<const f32x4*>(wrow + 16 * T * kWH + 16 * (2 * kn + h));
+                    for (int p = 0; p < 3; ++p) wb[(ks + 1) & 1][T][p] = wp[((size_t)(T * (kWT / 2) + kn) * 3 + p) * 64];
                 bf16x8 b[NS][3];
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
@@ -136,12 +138,9 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
                         b[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xc.xb16[lb][s][p][ks][lane][0]));
 #pragma unroll
                 for (int T = 0; T < kWTW; ++T) {
-                    uint32_t pc[8][3];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) split3_bf16(wb[ks & 1][k >> 2][T][k & 3], pc[k]);
                     bf16x8 aw[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) aw[p] = mfma_b16_operand(pc, p);
+                    for (int p = 0; p < 3; ++p) aw[p] = __builtin_bit_cast(bf16x8, wb[ks & 1][T][p]);
 #pragma unroll
                     for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][2], acc[T][s]);
 #pragma unroll
@@ -425,7 +424,7 @@ void wide_dopri5_kernel(SolveArgs a) {   // (bf16 path: no register cap -- its p
         bool restart = false;
 #pragma unroll
         for (int m = 0; m < D; ++m) zz[m] = yi[m];
-        field_fwd_wide<D, HUTCH>(net, ws, xc, a.params, lane, w, sgn * ti, zz, ee, f, div);
+        field_fwd_wide<D, HUTCH>(net, ws, xc, a.params, lane, w, sgn * ti, zz, ee, f, div, reinterpret_cast<const u32x4*>(a.slab));
         #pragma unroll
         for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
         div -= res * (float)D;
@@ -593,9 +592,34 @@ hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, co
     return hipErrorNotSupported;
 }
 
+// The two hidden matrices as three bf16 pieces each, in the operand order of field_fwd_wide's bf16 path:
+// out[layer][Tout][k-step][piece][lane] = 8 bf16 of W[16 Tout + (lane & 15)][16 (2ks + (e >> 2)) + 4 (lane >> 4) + (e & 3)].
+// 786 KB at the head of the workspace's gradient region (the forward solve uses nothing else of it), once per launch.
+__global__ __launch_bounds__(256) void wide_split_weights_kernel(const float* __restrict__ params, int D, u32x4* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // [layer][Tout][k-step][lane]
+    if (idx >= 2 * kWT * (kWT / 2) * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) & 7, To = (idx >> 9) & 15, l = idx >> 13;
+    const float* w = params + make_layout(D, kWH).w(1 + l) + (size_t)(16 * To + (lane & 15)) * kWH + 4 * (lane >> 4);
+    uint32_t pc[8][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + 16 * (2 * ks + h));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) split3_bf16(v[r], pc[4 * h + r]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const u32x4 v = {(pc[0][p] >> 16) | pc[1][p], (pc[2][p] >> 16) | pc[3][p], (pc[4][p] >> 16) | pc[5][p], (pc[6][p] >> 16) | pc[7][p]};
+        out[((size_t)((l * kWT + To) * (kWT / 2) + ks) * 3 + p) * 64 + lane] = v;
+    }
+}
+
 template <int D, bool HUTCH>
 static hipError_t wide_solve_t(const SolveArgs& a, int solver, bool global, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
+    if (kWideB16 && solver == CNF_SOLVER_DOPRI5)
+        hipLaunchKernelGGL(wide_split_weights_kernel, dim3(2 * kWT * (kWT / 2) * 64 / 256), dim3(256), 0, s, a.params, D,
+                           reinterpret_cast<u32x4*>(a.slab));
     dbg_timing_begin(s);
     if (solver != CNF_SOLVER_DOPRI5) {
         hipLaunchKernelGGL((wide_rk4_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
