@@ -1,11 +1,16 @@
 """GPU parity of the forward HIP path against the CPU oracle (same weights, same inputs), through the C ABI.
 
-Tolerances (fp32 path):
-  * one evaluation of the dynamics: 1e-5 relative (north_star, Appendix C);
+Tolerances:
+  * one evaluation of the dynamics: 1e-5 relative (north_star, Appendix C) -- the fp32-MFMA path (cnf_eval_field) and the
+    bf16-split arithmetic of the forward dopri5 solves (cnf_debug_eval_field_b16) alike, the latter also no further from
+    float64 than the former;
   * fixed-step RK4: z and logp within 1e-5 relative of the oracle (north_star criterion 1);
-  * dopri5: identical accepted/rejected step counts (hence NFE) and |delta logp| <= 5e-4, |delta z| <= 5e-4*scale
-    (controller decisions are taken on batch means, so summation-order noise cannot flip them except at
-    exact ties; a test that flips would show up as an NFE mismatch).
+  * dopri5, batch-global: identical accepted/rejected step counts (hence NFE) and |delta logp| <= 5e-4, |delta z| <=
+    5e-4*scale (controller decisions are taken on batch means, so rounding noise cannot flip them except within
+    rounding of the threshold; the stiff multimodal field, where a tenth of the attempts are such, is held to 3 % of
+    the attempts and to the float64 tight-tolerance solution instead);
+  * dopri5, tile-local (16-row control groups): attempt counts within 3 attempts / 3 %, mean error against the float64
+    tight-tolerance solution no larger than 2x the oracle's.
 """
 import copy
 
