@@ -26,7 +26,6 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F_EVAL_D2 = 2 * 8448 + 2 * 2 * (8448 - 2 * 64)   # 50 176 FLOP per sample-eval (d=2, H=64^3, exact div)
 EVAL_LAUNCH_ROWS = 1 << 22   # rows per tile-local launch (the tail of a launch idles CUs: 2^18 -> 2^22 rows is +4 %)
@@ -49,9 +48,48 @@ def parse():
     p.add_argument("--mode", type=str, default="fused", choices=["fused", "graph", "eager"],
                    help="fused: gu_ffjord.FusedTrainStep (solves + cnf_nll_loss + cnf_adam_step, one hipGraph replay per "
                         "iteration); graph: autograd + torch.optim.Adam loop captured as one hipGraph; eager: that loop, launched eagerly")
-    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,wide,pair,cpu",
-                   help="comma list of the additional measurements to run: roofline, late, eval, d16, wide, pair, cpu ('' = none)")
+    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,wide,pair,cpu,config1,repeats",
+                   help="comma list of the additional measurements to run: roofline, late, eval, d16, wide, pair, cpu, config1, "
+                        "repeats ('' = none)")
+    p.add_argument("--repeats", type=int, default=5, help="extra repeats of the timed loop (fresh seed-1 model each) for the spread keys")
+    p.add_argument("--cpu-late-iters", type=int, default=1,
+                   help="CPU-oracle iterations on the late_training field (tens of seconds each; 0 = skip)")
+    p.add_argument("--config1-cpu-iters", type=int, default=100, help="CPU-oracle iterations of BASELINE config 1 (gu_num=1)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="rehearse launch, rendezvous and the JSON contract without a GPU (CPU test of the --gpus N spawn path)")
     return p.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh processes of this script, one rank per GPU, the way
+    the reference runs one trial per cuda:i (/root/reference/hyperopt_wgan.py:642-643,739).  Runs BEFORE anything in this
+    process has touched HIP (no torch.cuda call so far) and never execs: the ranks are children, rank 0's stdout (the JSON
+    line) is this process's stdout, and the exit code is the first non-zero one of the children."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:          # a dead rank leaves the others waiting in a collective
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def embed_trained_multimodal(model):
@@ -90,11 +128,32 @@ def train_step(model, opt, x, gu_ffjord):
     return loss, blk.last_stats["forward"], blk.last_stats["backward"]
 
 
+def dry_run(args, world, rank):
+    """No GPU: the launch / rendezvous / one-JSON-line contract only (tests/test_bench_launch.py)."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        assert t.item() == world * (world + 1) / 2
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "CNF train iters/s (B=2048, d=2)", "value": None, "unit": "iters/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True}), flush=True)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the CNF path is a HIP kernel with no CPU fallback")
     # BENCH_DIST_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then share

@@ -23,7 +23,7 @@ class CnfNetDesc(ctypes.Structure):
 class CnfSolverOpts(ctypes.Structure):
     _fields_ = [("solver", ctypes.c_int32), ("rtol", ctypes.c_float), ("atol", ctypes.c_float),
                 ("step_size", ctypes.c_float), ("tile_rows", ctypes.c_int32), ("max_steps", ctypes.c_int32),
-                ("flags", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("after", ctypes.c_void_p)]
 
 
 class CnfAdamOpts(ctypes.Structure):
@@ -87,7 +87,7 @@ def load_library(act="tanh"):
     lib.cnf_nll_loss.restype = ctypes.c_int
     lib.cnf_nll_loss.argtypes = [P, P, I64, ctypes.c_int32, P, P, P, VP]
     lib.cnf_adam_step.restype = ctypes.c_int
-    lib.cnf_adam_step.argtypes = [P, P, P, P, P, I64, ctypes.POINTER(CnfAdamOpts), VP]
+    lib.cnf_adam_step.argtypes = [P, P, P, P, P, I64, ctypes.POINTER(CnfAdamOpts), P, VP]
     lib.cnf_debug_kernel_timing.restype = ctypes.c_int
     lib.cnf_debug_kernel_timing.argtypes = [ctypes.c_int]
     lib.cnf_debug_last_kernel_ms.restype = ctypes.c_int
@@ -201,11 +201,27 @@ FLAG_CLEAN = 1   # CNF_FLAG_CLEAN, include/cnf_hip.h
 FLAG_SPREAD = 2  # CNF_FLAG_SPREAD
 
 
-def make_opts(solver="dopri5", rtol=1e-5, atol=1e-5, step_size=None, tile_rows=0, max_steps=0, flags=0):
+def make_opts(solver="dopri5", rtol=1e-5, atol=1e-5, step_size=None, tile_rows=0, max_steps=0, flags=0, after=None):
+    """after: the stats words (8 int32 on the device) of the solve whose output this one consumes; a non-zero status there
+    makes this solve exit at once with the same status (CnfSolverOpts.after, include/cnf_hip.h)."""
     if solver not in SOLVER_IDS:
         raise CnfError("solver %r is not built into the HIP path (have: %s)" % (solver, ", ".join(SOLVER_IDS)))
     return CnfSolverOpts(SOLVER_IDS[solver], float(rtol), float(atol), float(step_size or 0.0), int(tile_rows), int(max_steps),
-                         int(flags))
+                         int(flags), _stats_ptr(after))
+
+
+def _stats_ptr(words):
+    if words is None:
+        return None
+    if not (torch.is_tensor(words) and words.is_cuda and words.dtype == torch.int32 and words.numel() == 8 and words.is_contiguous()):
+        raise CnfError("a stats block must be 8 contiguous int32 words on the HIP device")
+    return words.data_ptr()
+
+
+def with_after(opts, words):
+    """A copy of `opts` whose `after` names the stats block `words` (or nothing)."""
+    return CnfSolverOpts(opts.solver, opts.rtol, opts.atol, opts.step_size, opts.tile_rows, opts.max_steps, opts.flags,
+                         _stats_ptr(words))
 
 
 def _stats_block(stats, device):
@@ -344,8 +360,9 @@ def nll_loss(z, delta_logp, want_grads=True):
     return loss, gz, gl
 
 
-def adam_step(params, grad, exp_avg, exp_avg_sq, state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-    """In-place torch.optim.Adam update of a flat fp32 vector; `state` = 2 int32 on the device ({step, internal})."""
+def adam_step(params, grad, exp_avg, exp_avg_sq, state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, guard=None):
+    """In-place torch.optim.Adam update of a flat fp32 vector; `state` = 2 int32 on the device ({step, internal}).
+    guard: stats words of the solve that produced `grad`; a non-zero status there turns the update into a no-op."""
     lib = load_library()
     n = params.numel()
     for name, t in (("params", params), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
@@ -356,7 +373,7 @@ def adam_step(params, grad, exp_avg, exp_avg_sq, state, lr=1e-3, betas=(0.9, 0.9
     o = CnfAdamOpts(float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay))
     with torch.cuda.device(params.device):
         _check(lib.cnf_adam_step(_ptr(params), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(state), n,
-                                 ctypes.byref(o), _stream()), lib)
+                                 ctypes.byref(o), ctypes.c_void_p(_stats_ptr(guard)), _stream()), lib)
 
 
 def debug_fill_lds(pattern=0x7FC00000, device=None):

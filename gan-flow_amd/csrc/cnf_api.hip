@@ -20,7 +20,8 @@ hipError_t launch_split_aug(int D, bool hutch, const SolveArgs& a, float t, cons
 // loss and optimizer step, cnf_train.hip
 hipError_t launch_nll_loss(const float* z, const float* dlogp, long rows, int dim, float* loss_out, float* grad_z,
                            float* grad_dlogp, hipStream_t s);
-hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state, long n, const CnfAdamOpts& o, hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state, long n, const CnfAdamOpts& o,
+                       const CnfStats* guard, hipStream_t s);
 hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s);
 // hidden width 256, forward path (cnf_wide.hip)
 hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
@@ -186,15 +187,19 @@ int cnf_debug_eval_field_b16(const CnfNetDesc* net, const float* params, float t
     return 0;
 }
 
+// what a FORWARD solve touches of its workspace: the granules, and at hidden width 256 the bf16 weight pieces behind them
+static size_t fwd_workspace_need(const CnfNetDesc* net) { return kGranBytes + (is_wide(net) ? kWidePieceBytes : 0); }
+
+// need_override > 0: the workspace is checked against that many bytes instead of cnf_workspace_bytes (cnf_solve_fwd_static)
 static int fill_common(const char* who, const CnfNetDesc* net, const float* params, int64_t rows, float t0, float t1,
                        const CnfSolverOpts* opts, void* workspace, size_t workspace_bytes, CnfStats* stats,
-                       cnf::SolveArgs& a, bool& global) {
+                       cnf::SolveArgs& a, bool& global, size_t need_override = 0) {
     if (check_net(net)) return 1;
     if (!params || !opts || !stats || !workspace) return fail("%s: NULL pointer", who);
     if (rows <= 0) return fail("%s: rows must be positive (got %ld)", who, (long)rows);
     if (!(t0 != t1) || !std::isfinite(t0) || !std::isfinite(t1)) return fail("%s: t0 and t1 must be finite and distinct", who);
     if (((uintptr_t)workspace & 15) != 0) return fail("%s: workspace must be 16-byte aligned", who);
-    const size_t need = cnf_workspace_bytes(net, rows);
+    const size_t need = need_override ? need_override : cnf_workspace_bytes(net, rows);
     if (workspace_bytes < need) return fail("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
     a = cnf::SolveArgs{};
     a.params = params;
@@ -210,6 +215,9 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
     a.n_grid = 1;
     a.residual = is_residual(net) ? 1 : 0;
     a.step_size = 0.f;
+    a.after = opts->after;
+    if (opts->after == stats) return fail("%s: opts->after must be another block than this solve's stats", who);
+    if (opts->flags & ~(CNF_FLAG_CLEAN | CNF_FLAG_SPREAD)) return fail("%s: unknown bits in opts->flags (0x%x)", who, (unsigned)opts->flags);
     global = true;
     if (opts->solver == CNF_SOLVER_DOPRI5) {
         if (!(opts->rtol > 0.f) || !(opts->atol > 0.f)) return fail("%s: dopri5 needs rtol > 0 and atol > 0", who);
@@ -250,15 +258,21 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
     return 0;
 }
 
-int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, const float* logp0, const float* e,
-                  int64_t rows, float t0, float t1, const CnfSolverOpts* opts, float* z_out, float* logp_out,
-                  void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream) {
+}  // extern "C"
+
+namespace {
+// cnf_solve_fwd and cnf_solve_fwd_static.  library_scratch: `workspace` is the library's own static array, which
+// other calls have used: its granules are always cleared (CNF_FLAG_CLEAN then only spares the stats block's memset)
+int solve_fwd_impl(const char* who, bool library_scratch, const CnfNetDesc* net, const float* params, const float* x,
+                   const float* logp0, const float* e, int64_t rows, float t0, float t1, const CnfSolverOpts* opts,
+                   float* z_out, float* logp_out, void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream) {
     cnf::SolveArgs a;
     bool global;
-    if (fill_common("cnf_solve_fwd", net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
-    if (!x || !z_out || !logp_out) return fail("cnf_solve_fwd: NULL pointer");
+    const size_t need = library_scratch && net && supported(net) ? fwd_workspace_need(net) : 0;
+    if (fill_common(who, net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global, need)) return 1;
+    if (!x || !z_out || !logp_out) return fail("%s: NULL pointer", who);
     const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
-    if (hutch && !e) return fail("cnf_solve_fwd: Hutchinson divergence needs the probe e");
+    if (hutch && !e) return fail("%s: Hutchinson divergence needs the probe e", who);
     a.x = x;
     a.logp0 = logp0;
     a.e = e;
@@ -268,20 +282,27 @@ int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, co
     // CNF_FLAG_CLEAN: batch-global dopri5 kernels that clean up after themselves (cnf_split.hip, cnf_wide.hip)
     const bool clean = (opts->flags & CNF_FLAG_CLEAN) && opts->solver == CNF_SOLVER_DOPRI5 && global &&
                        (is_wide(net) || use_split(net, rows));
+    if (is_wide(net) && ((uintptr_t)params & 15) != 0) return fail("%s: params must be 16-byte aligned for hidden width 256", who);
     hipError_t err = hipSuccess;
-    if (!clean) {
-        err = hipMemsetAsync(workspace, 0, kGranBytes, s);
-        if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
-    }
-    if (is_wide(net) && ((uintptr_t)params & 15) != 0)
-        return fail("cnf_solve_fwd: params must be 16-byte aligned for hidden width 256");
+    if (!clean || library_scratch) err = hipMemsetAsync(workspace, 0, kGranBytes, s);
+    if (!clean && err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
     if (err == hipSuccess) {
         if (is_wide(net)) err = cnf::launch_wide_solve(net->dim, hutch, a, opts->solver, global, s);
         else if (opts->solver == CNF_SOLVER_DOPRI5 && global && use_split(net, rows)) err = cnf::launch_split_fwd(net->dim, hutch, a, s);
         else err = cnf::launch_solve_fwd(net->dim, hutch, a, opts->solver, global, s);
     }
-    if (err != hipSuccess) return fail("cnf_solve_fwd: launch failed: %s", hipGetErrorString(err));
+    if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, const float* logp0, const float* e,
+                  int64_t rows, float t0, float t1, const CnfSolverOpts* opts, float* z_out, float* logp_out,
+                  void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream) {
+    return solve_fwd_impl("cnf_solve_fwd", false, net, params, x, logp0, e, rows, t0, t1, opts, z_out, logp_out, workspace,
+                          workspace_bytes, stats, stream);
 }
 
 int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const float* z, const float* e, const float* a_z,
@@ -420,7 +441,7 @@ int cnf_solve_bwd_train(const CnfNetDesc* net, float* params, const float* z1, c
     const cnf::ParamLayout L = cnf::make_layout(net->dim, net->hidden);
     const int tiles = (int)((rows + cnf::kRows - 1) / cnf::kRows);
     hipError_t err = cnf::launch_adam_slabs(a.slab, tiles, L.total, a.spread ? L.w(2) : 0, grad_params, params, exp_avg,
-                                            exp_avg_sq, adam_state, *adam, (hipStream_t)stream);
+                                            exp_avg_sq, adam_state, *adam, stats, (hipStream_t)stream);
     if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
     return 0;
 }
@@ -435,14 +456,14 @@ int cnf_nll_loss(const float* z, const float* delta_logp, int64_t rows, int32_t 
 }
 
 int cnf_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* state, int64_t n,
-                  const CnfAdamOpts* opts, void* stream) {
+                  const CnfAdamOpts* opts, const CnfStats* guard, void* stream) {
     if (!params || !grad || !exp_avg || !exp_avg_sq || !state || !opts) return fail("cnf_adam_step: NULL pointer");
     if (n <= 0) return fail("cnf_adam_step: n must be positive (got %ld)", (long)n);
     if (!(opts->lr >= 0.) || !(opts->beta1 >= 0. && opts->beta1 < 1.) || !(opts->beta2 >= 0. && opts->beta2 < 1.) ||
         !(opts->eps >= 0.) || !(opts->weight_decay >= 0.))
         return fail("cnf_adam_step: invalid hyper-parameters (lr %g, betas %g %g, eps %g, weight_decay %g)", opts->lr,
                     opts->beta1, opts->beta2, opts->eps, opts->weight_decay);
-    hipError_t err = cnf::launch_adam(params, grad, exp_avg, exp_avg_sq, state, n, *opts, (hipStream_t)stream);
+    hipError_t err = cnf::launch_adam(params, grad, exp_avg, exp_avg_sq, state, n, *opts, guard, (hipStream_t)stream);
     if (err != hipSuccess) return fail("cnf_adam_step: launch failed: %s", hipGetErrorString(err));
     return 0;
 }

@@ -588,7 +588,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
     BigAcc acc;
     acc.zero();
 
-    for (;;) {
+    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    for (; status == 0;) {
         float zz[D], az[D], f[D], vz[D], div, k[C];
         bool restart = false;
 #pragma unroll

@@ -84,6 +84,10 @@ constexpr int kEvalB16NW = CNF_EVAL_B16_NW, kEvalB16Waves = CNF_EVAL_B16_WAVES;
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D > 2 ? 1 : kEvalWaves, D > 2 ? 8 : kEvalWaves)))
 void rk4_kernel(SolveArgs a) {
+    if (a.after && a.after->status != 0) {   // CnfSolverOpts.after: the solve whose output this one consumes failed
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&a.stats->status, a.after->status);
+        return;
+    }
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLds<D> net;
     __shared__ WaveLds<D> wl[kNW];
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(NW * 64)
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[C];  // initial-step scale, atol + |y0| * rtol
 
-    for (;;) {
+    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    for (; status == 0;) {
         float zz[D], f[D], div, k[C];
         bool restart = false;
 #pragma unroll

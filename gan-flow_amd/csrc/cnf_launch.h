@@ -33,6 +33,7 @@ struct SolveArgs {
                           // loss goes here
     int residual;         // CNF_DIV_RESIDUAL: the dynamics are f(z) - z (ODEfunc(residual=True))
     int keep_slabs;       // adjoint: leave the per-workgroup gradient slabs for launch_adam_slabs (no reduction kernel)
+    const CnfStats* after;  // CnfSolverOpts.after (nullable): exit at once with that block's status when it is non-zero
 };
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,

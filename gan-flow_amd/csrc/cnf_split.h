@@ -133,8 +133,9 @@ __device__ __forceinline__ void hidden_b16(const uint32_t (*xb16)[3][2][64][4], 
 
 // sum of the workgroups' gradient slabs in a fixed order (kernel in cnf_split.hip)
 hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hipStream_t s, int split_at = 0);
-// slab sum (as launch_reduce_slab) + Adam update of the P parameters in one kernel; grad_out may be null
+// slab sum (as launch_reduce_slab) + Adam update of the P parameters in one kernel; grad_out may be null; guard (nullable):
+// the stats block of the adjoint solve that wrote the slabs -- a non-zero status there makes the kernel a no-op
 hipError_t launch_adam_slabs(const float* slab, int ntiles, int P, int split_at, float* grad_out, float* p, float* m, float* v,
-                             int* state, const CnfAdamOpts& o, hipStream_t s);
+                             int* state, const CnfAdamOpts& o, const CnfStats* guard, hipStream_t s);
 
 }  // namespace cnf

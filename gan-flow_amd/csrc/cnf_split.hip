@@ -222,7 +222,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
 
     Prof pr;
     pr.mark(15);
-    for (;;) {
+    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    for (; status == 0;) {
         float zz[D], f[D], div, k[C];
         bool restart = false;
 #pragma unroll
@@ -911,7 +912,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     glast.zero();
     int i_first = 1, i_last = 2;  // which of sb.small[1], sb.small[2] holds the first / seventh stage's sums
 
-    for (;;) {
+    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    for (; status == 0;) {
         float zz[D], az[D], f[D], vz[D], div, k[C];
         bool restart = false;
 #pragma unroll
@@ -1169,7 +1171,10 @@ hipError_t launch_reduce_slab(const float* slab, int nwg, int P, float* out, hip
 __global__ __launch_bounds__(256) void adam_slab_kernel(const float* __restrict__ slab, int nwg, int P, int split_at,
                                                         float* __restrict__ grad_out, float* __restrict__ p,
                                                         float* __restrict__ m, float* __restrict__ v, int* __restrict__ state,
-                                                        CnfAdamOpts o) {
+                                                        CnfAdamOpts o, const CnfStats* __restrict__ guard) {
+    // the adjoint solve (or a solve before it, CnfSolverOpts.after) failed: its slabs are stale or garbage.  No update, no
+    // step: parameters, moments and step count keep their bits (every workgroup reads the same word: uniform exit)
+    if (guard && guard->status != 0) return;
     __shared__ float part[4][64];
     __shared__ float corr[2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1202,9 +1207,9 @@ __global__ __launch_bounds__(256) void adam_slab_kernel(const float* __restrict_
 }
 
 hipError_t launch_adam_slabs(const float* slab, int ntiles, int P, int split_at, float* grad_out, float* p, float* m, float* v,
-                             int* state, const CnfAdamOpts& o, hipStream_t s) {
+                             int* state, const CnfAdamOpts& o, const CnfStats* guard, hipStream_t s) {
     hipLaunchKernelGGL(adam_slab_kernel, dim3((P + 63) / 64), dim3(256), 0, s, slab, ntiles, P, split_at, grad_out, p, m, v,
-                       state, o);
+                       state, o, guard);
     return hipGetLastError();
 }
 

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[kC];
 
-    for (;;) {
+    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    for (; status == 0;) {
         f32x4 z4, f4;
         float div, k[kC];
         bool restart = false;
@@ -789,7 +790,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     glast.zero();
     int i_first = 1, i_last = 2;   // which of sb.small[1], sb.small[2] holds the first / seventh stage's sums
 
-    for (;;) {
+    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    for (; status == 0;) {
         f32x4 z4, az4, f4, vz4;
         float div, k[kCA];
         bool restart = false;

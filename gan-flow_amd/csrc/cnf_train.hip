@@ -45,7 +45,9 @@ constexpr int kAdamThreads = 256;
 
 __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v,
-                                                            int* __restrict__ state, long n, CnfAdamOpts o) {
+                                                            int* __restrict__ state, long n, CnfAdamOpts o,
+                                                            const CnfStats* __restrict__ guard) {
+    if (guard && guard->status != 0) return;   // the solve that produced g failed: no update, no step (uniform exit)
     __shared__ float corr[2];
     AdamCoef c;
     const int step = adam_begin(state, o, corr, c);
@@ -74,9 +76,10 @@ hipError_t launch_nll_loss(const float* z, const float* dlogp, long rows, int di
     return hipGetLastError();
 }
 
-hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state, long n, const CnfAdamOpts& o, hipStream_t s) {
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state, long n, const CnfAdamOpts& o,
+                       const CnfStats* guard, hipStream_t s) {
     const int blocks = (int)((n + kAdamThreads - 1) / kAdamThreads);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kAdamThreads), 0, s, p, g, m, v, state, n, o);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kAdamThreads), 0, s, p, g, m, v, state, n, o, guard);
     return hipGetLastError();
 }
 

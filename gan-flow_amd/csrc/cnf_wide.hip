@@ -274,6 +274,10 @@ __global__ __launch_bounds__(kThreads) void wide_field_kernel(const float* __res
 // ---- fixed-grid RK4 (3/8 rule), as rk4_kernel in cnf_fwd.hip ---------------------------------------------------
 template <int D, bool HUTCH>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void wide_rk4_kernel(SolveArgs a) {
+    if (a.after && a.after->status != 0) {   // CnfSolverOpts.after: the solve whose output this one consumes failed
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&a.stats->status, a.after->status);
+        return;
+    }
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = D + 1;
@@ -419,7 +423,8 @@ void wide_dopri5_kernel(SolveArgs a) {   // (bf16 path: no register cap -- its p
         return true;
     };
 
-    for (;;) {
+    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    for (; status == 0;) {
         float zz[D], f[D], div, k[C];
         bool restart = false;
 #pragma unroll

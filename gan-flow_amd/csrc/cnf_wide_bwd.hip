@@ -588,7 +588,8 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
     float sc[CE];
     int i_first = 0, i_last = 6;   // slots of the first / seventh stage's sums; stages 1..5 use slots 1..5
 
-    for (;;) {
+    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    for (; status == 0;) {
         float zz[D], az[D], f[D], vz[D], div, k[C];
         bool restart = false;
 #pragma unroll

@@ -205,14 +205,18 @@ class FusedTrainStep:
 
     def _iteration(self):
         nat = self._native
-        z, lp, tape = self.static_x, None, []
+        # every solve names the stats block of the solve before it (CnfSolverOpts.after): a failure anywhere makes all
+        # later solves of the iteration exit at once with that status, and the Adam updates skip themselves -- the
+        # parameters are never updated from the garbage a failed solve leaves behind
+        z, lp, tape, prev = self.static_x, None, [], None
         for i, blk in enumerate(self.blocks):
             net, t0, t1, opts, e = blk.solve_plan(z, reset_counter=False)
             if opts.solver == 0 and opts.tile_rows == 0:
                 opts.flags |= nat.FLAG_CLEAN
             if self.spread:
                 opts.flags |= nat.FLAG_SPREAD
-            z, lp, _ = nat.solve_fwd(net, self.flats[i], z, lp, t0, t1, opts, e, stats=self.stats[i, 0], workspace=self.workspace)
+            z, lp, prev = nat.solve_fwd(net, self.flats[i], z, lp, t0, t1, nat.with_after(opts, prev), e, stats=self.stats[i, 0],
+                                        workspace=self.workspace)
             tape.append((net, t0, t1, opts, e, z, lp))
         # the tail: cnf_solve_bwd_train (adjoint + slab sum + Adam in two kernels; for the last block also the loss and its
         # cotangents) where it is built -- hidden width 64, <= 4096 rows -- else cnf_nll_loss, cnf_solve_bwd, cnf_adam_step
@@ -223,15 +227,16 @@ class FusedTrainStep:
             loss, gz, gl = nat.nll_loss(z, lp)
         for i in range(last, -1, -1):
             net, t0, t1, opts, e, z1, lp1 = tape[i]
+            opts = nat.with_after(opts, prev)
             if fused[i]:
-                gz, gl, _, l_, _ = nat.solve_bwd_train(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, self.exp_avg[i],
-                                                       self.exp_avg_sq[i], self.adam_state[i], e, stats=self.stats[i, 1],
-                                                       workspace=self.workspace, **self.hyper)
+                gz, gl, _, l_, prev = nat.solve_bwd_train(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, self.exp_avg[i],
+                                                          self.exp_avg_sq[i], self.adam_state[i], e, stats=self.stats[i, 1],
+                                                          workspace=self.workspace, **self.hyper)
                 loss = l_ if l_ is not None else loss
             else:
-                gz, gl, gp, _ = nat.solve_bwd(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, e, stats=self.stats[i, 1],
-                                              workspace=self.workspace)
-                nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], **self.hyper)
+                gz, gl, gp, prev = nat.solve_bwd(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, e, stats=self.stats[i, 1],
+                                                 workspace=self.workspace)
+                nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], guard=prev, **self.hyper)
         return loss
 
     def __call__(self, x):
@@ -503,6 +508,8 @@ def main(argv=None):
             t_last, itr_last = time.time(), itr
         if args.max_seconds and time.time() - t_start > args.max_seconds:
             torch.cuda.synchronize()
+            if fused is not None:
+                fused.check()          # never overwrite the last good checkpoint after a failed solve
             checkpoint(itr)
             logger.info("time limit reached at iteration %d: checkpoint written" % itr)
             break

@@ -22,6 +22,7 @@ class _Solve(torch.autograd.Function):
         z1, logp1, stats = _native.solve_fwd(net, flat_params.detach(), z.detach(), logp.detach(), t0, t1, opts, e)
         block._after_solve(stats, backward=False)
         ctx.block, ctx.t0, ctx.t1, ctx.opts, ctx.net = block, t0, t1, opts, net
+        ctx.fwd_stats = stats      # device words: the adjoint solve exits at once if this solve failed (opts.after)
         ctx.save_for_backward(z1, logp1, flat_params.detach(), e if e is not None else z.new_zeros(0))
         return z1, logp1
 
@@ -32,7 +33,7 @@ class _Solve(torch.autograd.Function):
         grad_z = torch.zeros_like(z1) if grad_z is None else grad_z
         grad_logp = torch.zeros_like(logp1) if grad_logp is None else grad_logp
         gx, gl, gp, stats = _native.solve_bwd(ctx.net, flat_params, z1, logp1, grad_z, grad_logp, ctx.t0, ctx.t1,
-                                              ctx.opts, e)
+                                              _native.with_after(ctx.opts, ctx.fwd_stats), e)
         ctx.block._after_solve(stats, backward=True)
         return gx, gl, gp, None, None, None, None, None, None
 

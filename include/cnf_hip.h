@@ -53,6 +53,8 @@ enum { CNF_DIV_EXACT = 0, CNF_DIV_HUTCHINSON = 1 };
  * reduced by dim accordingly (ffjord/lib/layers/odefunc.py, UPSTREAM-RECALL; the reference's runs use False). */
 enum { CNF_DIV_RESIDUAL = 256 };
 
+struct CnfStats;
+
 /* Solver options: the keyword arguments of torchdiffeq.odeint (rtol, atol, method, options). */
 typedef struct CnfSolverOpts {
     int32_t solver;      /* CNF_SOLVER_*                                                          */
@@ -62,7 +64,15 @@ typedef struct CnfSolverOpts {
                             semantics); 16 = every 16-row tile controls its own step (throughput
                             evaluation mode)                              */
     int32_t max_steps;   /* dopri5 attempt limit per solve (0 = 1<<20)                            */
-    int32_t flags;       /* CNF_FLAG_* (0 = none)                                                 */
+    int32_t flags;       /* CNF_FLAG_* (0 = none); unknown bits are rejected                      */
+    const struct CnfStats *after; /* NULL, or the (device) CnfStats block of the solve whose OUTPUT this solve
+                            consumes -- the forward solve of the previous block, the forward solve an adjoint
+                            solve reverses, the adjoint solve of the next block.  If that block's status is
+                            non-zero when this kernel starts (stream order), it exits at once with the same
+                            status and touches no output: a failure travels down a chain of solves without
+                            a host read-back, and the Adam updates at its end skip themselves.  Must not be
+                            this call's own `stats`.  (No counterpart in the reference, which raises from
+                            Python at the failing step.)                                              */
 } CnfSolverOpts;
 
 /* CNF_FLAG_CLEAN: the caller guarantees that the first 16 KiB + 64 bytes of `workspace` are zero and that
@@ -163,8 +173,10 @@ typedef struct CnfAdamOpts {
 /*   params, exp_avg, exp_avg_sq (n floats each) are updated in place from grad (n floats);
  *   state: 2 int32 in device memory, zeroed by the caller before the first step: {step count, internal};
  *   the step count is read and incremented on the device, so the call can be captured in a hipGraph.    */
+/*   guard (nullable): the CnfStats block of the solve that produced `grad`; if its status is non-zero the kernel
+ *   changes nothing -- parameters, moments and step count keep their bits (a failed solve leaves garbage gradients). */
 int cnf_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, int32_t *state,
-                  int64_t n, const CnfAdamOpts *opts, void *stream);
+                  int64_t n, const CnfAdamOpts *opts, const struct CnfStats *guard, void *stream);
 
 /* The tail of a training iteration for one CNF block in two kernels: the adjoint solve of cnf_solve_bwd, then the sum
  * of its per-workgroup gradient partials with the Adam update of cnf_adam_step as that kernel's epilogue (what the
@@ -174,8 +186,9 @@ int cnf_adam_step(float *params, const float *grad, float *exp_avg, float *exp_a
  *     grad_z1 = z1 / rows and grad_logp1 = 1 / rows, formed inside the adjoint kernel, and stores that loss
  *     (cnf_nll_loss's value up to summation order) to loss_out: for the LAST block of a flow this replaces cnf_nll_loss;
  *   - grad_params may be NULL (the summed gradient is then not stored anywhere).
- * `params` is updated in place AFTER the solve has read it.  Hidden width 64, at most 4096 rows; otherwise the call
- * fails and the three separate entry points are to be used.                                                   */
+ * `params` is updated in place AFTER the solve has read it -- unless the adjoint solve ended with a non-zero status
+ * (its own failure, or one inherited through opts->after): then the update kernel changes nothing.
+ * Hidden width 64, at most 4096 rows; otherwise the call fails and the three separate entry points are to be used.  */
 int cnf_solve_bwd_train(const CnfNetDesc *net, float *params, const float *z1, const float *logp1,
                         const float *e, const float *grad_z1, const float *grad_logp1, int64_t rows,
                         float t0, float t1, const CnfSolverOpts *opts, float *grad_x, float *grad_logp0,

@@ -51,7 +51,27 @@ def product_like(oracle_model, device, divergence_fn="brute_force", **kw):
     return m
 
 
+def embed_trained_multimodal(model):
+    """The reference's trained gu_num=8 weights (d=1 checkpoint fixture) placed in a d=2 net, nuisance coordinate
+    decoupled: bench.py's late-training stand-in, for oracle and product models alike."""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from bench import embed_trained_multimodal as embed
+    return embed(model)
+
+
 def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def elem_err(a, b, floor=1e-3):
+    """Per-element relative error with an absolute floor: max |a - b| / max(|b|, floor * max|b|).  rel_err divides by the
+    LARGEST element, so rows with small |b| can be far off in their own scale unnoticed; this one looks at every element in
+    its own scale, down to `floor` of the largest (below that an fp32 result carries no relative information)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    den = b.abs().clamp_min(floor * b.abs().max().clamp_min(1e-30))
+    return float(((a - b).abs() / den).max())

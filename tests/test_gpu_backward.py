@@ -149,6 +149,93 @@ def test_solve_bwd_matches_oracle_adjoint(case, rows):
     assert e_gx < 2e-4 and e_gp < 2e-4
 
 
+_STIFF_ORACLE = {}
+
+
+def _stiff_case(dim):
+    """x + float64 tight-tolerance gradients (tests/golden/stiff_adjoint_d{1,2}.npz, make_stiff_adjoint_vectors.py) and the
+    fp32 oracle's adjoint on the same rows (12 s of CPU per case, computed once per process)."""
+    import numpy as np
+    import os
+    from _helpers import GOLDEN, embed_trained_multimodal, fixture_state_dict
+    if dim not in _STIFF_ORACLE:
+        a = np.load(os.path.join(GOLDEN, "stiff_adjoint_d%d.npz" % dim))
+        m = oracle.build_cnf(dim)
+        if dim == 1:
+            m.load_state_dict(fixture_state_dict("multimodal"))
+        else:
+            embed_trained_multimodal(m)
+        x = torch.from_numpy(a["x"])
+        ref32 = _oracle_train_grads(m, x)
+        _STIFF_ORACLE[dim] = (m, x, {k: torch.from_numpy(np.asarray(a[k])) for k in a.files}, ref32)
+    return _STIFF_ORACLE[dim]
+
+
+@pytest.mark.parametrize("dim,spread,train", [(1, False, False), (1, True, False), (2, False, False), (2, True, False),
+                                              (2, True, True)])
+def test_solve_bwd_stiff_trained_field(dim, spread, train):
+    """The adjoint solve where BASELINE config 2 spends its time: the reference's trained gu_num=8 field (checkpoint
+    weights; d = 2: embedded as bench.py's late_training leg does), NFE ~1.5-2k per solve, every seventh attempt rejected.
+    Accept/reject decisions fall within fp32 rounding there, so the kernel's step sequence is not the oracle's.  Bars, as
+    for the stiff forward solves: attempt counts within 3 % of the oracle's; gradients no further from the float64
+    rtol = atol = 1e-9 adjoint (golden fixture) than 2x the fp32 oracle's own distance, per parameter block.
+    Covers commit-on-accept across rejections, the FSAL theta-buffers, the last step's quadrature weights, the
+    two-workgroups-per-tile split, and cnf_solve_bwd_train's in-kernel NLL cotangents."""
+    nat = _native()
+    m, x, gold, (loss_o, z_o, dl_o, gx_o, gp_o, st_o) = _stiff_case(dim)
+    rows = x.shape[0]
+    blk = m.chain[0]
+    T = float(blk.sqrt_end_time.detach() * blk.sqrt_end_time.detach())
+    net = nat.net_desc(dim, 64, 3, False)
+    params = _flat(m).to(DEV)
+    flags = nat.FLAG_SPREAD if spread else 0
+    opts = nat.make_opts("dopri5", 1e-5, 1e-5, flags=flags)
+    z1, l1, s_f = nat.solve_fwd(net, params, x.to(DEV), None, 0.0, T, opts)
+    if train:
+        p_work = params.clone()
+        mom, var = torch.zeros_like(params), torch.zeros_like(params)
+        state = torch.zeros(2, dtype=torch.int32, device=DEV)
+        gx, gl0, gp, loss, s_b = nat.solve_bwd_train(net, p_work, z1, l1, None, None, 0.0, T, opts, mom, var, state,
+                                                     want_grad_params=True, lr=0.0)
+        assert torch.equal(p_work, params) and int(state[0]) == 1        # lr = 0: a step was taken, nothing moved
+        assert abs(loss.item() - float(gold["loss"])) < 2e-3 * abs(float(gold["loss"]))
+    else:
+        gx, gl0, gp, s_b = nat.solve_bwd(net, params, z1, l1, z1 / rows, torch.full_like(l1, 1.0 / rows), 0.0, T, opts)
+    torch.cuda.synchronize()
+    s_f, s_b = nat.Stats(s_f), nat.Stats(s_b)
+    s_f.raise_for_status()
+    s_b.raise_for_status()
+    fo, bo = st_o["forward"], st_o["backward"]
+    n_f, n_b = s_f.n_accepted + s_f.n_rejected, s_b.n_accepted + s_b.n_rejected
+    n_fo, n_bo = fo["n_accepted"] + fo["n_rejected"], bo["n_accepted"] + bo["n_rejected"]
+    print("stiff adjoint d=%d spread=%d train=%d: fwd attempts hip %d+%d oracle %d+%d | bwd hip %d+%d oracle %d+%d"
+          % (dim, spread, train, s_f.n_accepted, s_f.n_rejected, fo["n_accepted"], fo["n_rejected"],
+             s_b.n_accepted, s_b.n_rejected, bo["n_accepted"], bo["n_rejected"]))
+    assert abs(n_f - n_fo) <= 0.03 * n_fo and abs(n_b - n_bo) <= 0.03 * n_bo
+    assert s_b.nfe == 2 + 6 * n_b and s_b.evals_run == s_b.nfe       # FSAL: nothing re-evaluated
+    assert torch.equal(gl0.cpu(), torch.full((rows, 1), 1.0 / rows))
+    gx64, gp64 = gold["grad_x"], gold["grad_theta"]
+    # grad_x: max-norm distance to the float64 solution, hip vs oracle
+    e_h, e_o = (gx.cpu().double() - gx64).abs().max().item(), (gx_o.double() - gx64).abs().max().item()
+    sx = gx64.abs().max().item()
+    print("   grad_x     |hip-f64| %.2e |oracle-f64| %.2e (scale %.2e)" % (e_h, e_o, sx))
+    assert e_h <= 2.0 * max(e_o, 2e-5 * sx)
+    # grad_theta: per parameter block
+    off, worst = 0, 0.0
+    sp = gp64.abs().max().item()
+    for name, p in _odefunc(m).diffeq.named_parameters():
+        n = p.numel()
+        ref = gp64[off:off + n]
+        b_h = (gp[off:off + n].cpu().double() - ref).abs().max().item()
+        b_o = (gp_o[off:off + n].double() - ref).abs().max().item()
+        scale = max(ref.abs().max().item(), 1e-3 * sp)
+        worst = max(worst, b_h / max(b_o, 2e-5 * scale))
+        assert b_h <= 2.0 * max(b_o, 2e-5 * scale), (name, b_h, b_o, scale)
+        off += n
+    e_h, e_o = (gp.cpu().double() - gp64).abs().max().item(), (gp_o.double() - gp64).abs().max().item()
+    print("   grad_theta |hip-f64| %.2e |oracle-f64| %.2e (scale %.2e); worst block ratio hip/oracle %.2f" % (e_h, e_o, sp, worst))
+
+
 def test_module_training_step_fills_parameter_grads():
     from gan_flow_amd import gu_ffjord
     mo = oracle_random_model(2, seed=11, scale=1.5)

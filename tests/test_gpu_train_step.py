@@ -140,6 +140,61 @@ def test_solve_bwd_train_equals_separate_calls(dim, blocks, rows, div):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("hidden,blocks,fail_in", [(64, 1, "forward"), (64, 1, "adjoint"), (64, 2, "forward"), (256, 1, "forward"),
+                                                   (256, 1, "adjoint")])
+def test_failed_solve_leaves_parameters_and_optimizer_untouched(hidden, blocks, fail_in):
+    """A solve that fails (here: max_num_steps exceeded) leaves its outputs unwritten.  Every later solve of the iteration
+    names the one before it (CnfSolverOpts.after) and exits at once with the same status, and the Adam kernels skip
+    themselves on a non-zero status: parameters, moments and step counts keep their bits, .check() raises, and the step
+    after the limit is lifted trains normally.  Both tails: cnf_solve_bwd_train (hidden 64) and cnf_solve_bwd +
+    cnf_adam_step (hidden 256)."""
+    from gan_flow_amd import _native, gu_ffjord
+    g = torch.Generator().manual_seed(3)
+    xs = [(torch.randn(512, 2, generator=g) * 1.5).to(DEV) for _ in range(3)]
+    torch.manual_seed(4)
+    model = gu_ffjord.build_model(2, dims=(hidden,) * 3, num_blocks=blocks).to(DEV).train()
+    step = gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=False)
+    step(xs[0])
+    assert step.check()[0] > 0 and step.step_count == 1
+    before = [t.clone() for t in step.flats + step.exp_avg + step.exp_avg_sq + step.adam_state]
+    # poison what a failed forward would leave unwritten, then make the first block's solves fail after one attempt
+    blk = model.chain[0]
+    if fail_in == "forward":
+        blk.solver_options["max_num_steps"] = 1
+        step(xs[1])
+    else:
+        # the adjoint alone: run the forward normally, then hand the adjoint a one-attempt limit through the raw calls
+        nat = _native
+        net, t0, t1, opts, e = blk.solve_plan(xs[1], reset_counter=False)
+        z1, l1, sf = nat.solve_fwd(net, step.flats[0], xs[1], None, t0, t1, opts)
+        lim = nat.make_opts("dopri5", 1e-5, 1e-5, max_steps=1, after=sf)
+        st = torch.zeros(8, dtype=torch.int32, device=DEV)
+        if hidden == 64:
+            nat.solve_bwd_train(net, step.flats[0], z1, l1, None, None, t0, t1, lim, step.exp_avg[0], step.exp_avg_sq[0],
+                                step.adam_state[0], stats=st, **step.hyper)
+        else:
+            gz, gl = z1 / 512, torch.full_like(l1, 1.0 / 512)
+            gx, _, gp, st = nat.solve_bwd(net, step.flats[0], z1, l1, gz, gl, t0, t1, lim)
+            nat.adam_step(step.flats[0], gp, step.exp_avg[0], step.exp_avg_sq[0], step.adam_state[0], guard=st, **step.hyper)
+        torch.cuda.synchronize()
+        assert nat.Stats(st).status == 3
+    torch.cuda.synchronize()
+    after = step.flats + step.exp_avg + step.exp_avg_sq + step.adam_state
+    for a, b in zip(before, after):
+        assert torch.equal(a, b)
+    if fail_in == "forward":
+        with pytest.raises(_native.CnfError, match="max_num_steps"):
+            step.check()
+        words = step.stats.cpu()
+        assert all(int(words[i, k, 0]) == 3 for i in range(blocks) for k in (0, 1))     # the status travelled down the chain
+        assert all(int(words[i, k, 1]) <= 8 for i in range(blocks) for k in (0, 1) if (i, k) != (0, 0))   # nothing else integrated
+        blk.solver_options.pop("max_num_steps")
+        step.stats.zero_()           # the status word is sticky under CNF_FLAG_CLEAN: the owner clears it after a failure
+    step(xs[2])
+    assert step.check()[0] > 0 and step.step_count == 2
+    assert not torch.equal(before[0], step.flats[0])
+
+
 def test_fused_train_step_two_blocks_hutchinson():
     """Stacked blocks + Hutchinson divergence: the loss gradient is chained through the blocks in reverse."""
     from gan_flow_amd import gu_ffjord

@@ -57,6 +57,30 @@ def test_calls_are_rejected_before_launch_with_a_message():
         _native.make_opts("adams")
 
 
+def test_integration_stub_binds_the_struct_the_library_reads():
+    """INTEGRATION.md Option B is what a maintainer copies: its ctypes structs must be the ones include/cnf_hip.h declares
+    (a short CnfSolverOpts makes the library read `flags` / `after` past the caller's struct)."""
+    import ctypes
+    import re
+    from gan_flow_amd import _native
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes, torch\n(.*?)```", text, re.S).group(1)
+    structs = block[:block.index("def _p(t)")].replace('_lib = ctypes.CDLL("libcnf_hip.so")', "")
+    ns = {"ctypes": ctypes}
+    exec(structs, ns)
+    for name in ("CnfNetDesc", "CnfSolverOpts"):
+        doc, ours = ns[name], getattr(_native, name)
+        assert [(f[0], f[1]) for f in doc._fields_] == [(f[0], f[1]) for f in ours._fields_], name
+        assert ctypes.sizeof(doc) == ctypes.sizeof(ours)
+    assert ctypes.sizeof(ns["CnfSolverOpts"]) == 40 and ns["CnfSolverOpts"].after.offset == 32
+    # and the header agrees: seven 4-byte fields, then the pointer
+    hdr = open(os.path.join(ROOT, "include", "cnf_hip.h")).read()
+    body = re.search(r"typedef struct CnfSolverOpts \{(.*?)\} CnfSolverOpts;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(\w+)\s*[;,]", body)
+    assert names == [f[0] for f in _native.CnfSolverOpts._fields_], names
+
+
 def test_product_modules_keep_reference_names():
     from gan_flow_amd import gu_ffjord
     from gan_flow_amd.lib.layers import CNF, ODEfunc, ODEnet, SequentialFlow, ConcatSquashLinear, RegularizedODEfunc
