@@ -42,7 +42,8 @@ STATUS_MESSAGES = {
 }
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
            "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
-           "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation", "cnf_debug_eval_field_b16")
+           "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation", "cnf_debug_eval_field_b16",
+           "cnf_solve_fwd_static", "cnf_static_scratch_bytes")
 
 
 def library_path(act="tanh"):
@@ -77,6 +78,10 @@ def load_library(act="tanh"):
     lib.cnf_debug_eval_field_b16.argtypes = [ND, P, F, P, P, I64, P, P, VP]
     lib.cnf_solve_fwd.restype = ctypes.c_int
     lib.cnf_solve_fwd.argtypes = [ND, P, P, P, P, I64, F, F, SO, P, P, VP, SZ, P, VP]
+    lib.cnf_solve_fwd_static.restype = ctypes.c_int
+    lib.cnf_solve_fwd_static.argtypes = [ND, P, P, P, P, I64, F, F, SO, P, P, P, VP]
+    lib.cnf_static_scratch_bytes.restype = SZ
+    lib.cnf_static_scratch_bytes.argtypes = []
     lib.cnf_eval_aug.restype = ctypes.c_int
     lib.cnf_eval_aug.argtypes = [ND, P, F, P, P, P, P, I64, P, P, P, P, VP, SZ, VP]
     lib.cnf_solve_bwd.restype = ctypes.c_int
@@ -264,6 +269,23 @@ def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None, workspace
         ws = _workspace(lib, net, rows, x.device) if workspace is None else _own_workspace(lib, net, rows, workspace)
         _check(lib.cnf_solve_fwd(ctypes.byref(net), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows, float(t0), float(t1),
                                  ctypes.byref(opts), _ptr(z), _ptr(logp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
+    return z, logp, stats
+
+
+def solve_fwd_static(net, params, x, logp0, t0, t1, opts, e=None, stats=None, out=None):
+    """cnf_solve_fwd_static: solve_fwd on the library's own static scratch (no workspace, nothing allocated by the call).
+    out: (z, logp) tensors to write into (a caller that must not allocate passes them); else fresh ones."""
+    lib = _lib_for(net)
+    x = _dev(x, "x")
+    rows = x.shape[0]
+    params = _dev(params, "params", (param_count(net),))
+    logp0 = _dev(logp0, "logp0", (rows, 1)) if logp0 is not None else None
+    e = _dev(e, "e", x.shape) if e is not None else None
+    z, logp = out if out is not None else (torch.empty_like(x), torch.empty(rows, 1, dtype=torch.float32, device=x.device))
+    stats = _stats_block(stats, x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.cnf_solve_fwd_static(ctypes.byref(net), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows, float(t0),
+                                        float(t1), ctypes.byref(opts), _ptr(z), _ptr(logp), _ptr(stats), _stream()), lib)
     return z, logp, stats
 
 

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 #include "cnf_launch.h"
@@ -303,6 +304,54 @@ int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, co
                   void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream) {
     return solve_fwd_impl("cnf_solve_fwd", false, net, params, x, logp0, e, rows, t0, t1, opts, z_out, logp_out, workspace,
                           workspace_bytes, stats, stream);
+}
+
+// ---- cnf_solve_fwd_static: the forward solve for callers that cannot allocate ------------------------------------------
+// The workspace of the forward solve lives in the library: one file-scope device array per GPU (each device that loads the
+// code object holds its own copy, at its own address, until the process ends).  `scratch` is the HOST-side stand-in of that
+// array -- never a device address: the per-device address comes from hipGetSymbolAddress, once per device, and only that
+// pointer is ever handed to a memset or a kernel.
+constexpr size_t kStaticScratchBytes = kGranBytes + kWidePieceBytes;   // 802 880 bytes: granules + the H = 256 weight pieces
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[64] = {nullptr};   // per device, filled on the first call with that device current
+
+int static_scratch(const char* who, void** out) {
+    int dev = -1;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return fail("%s: hipGetDevice failed: %s", who, hipGetErrorString(err));
+    if (dev < 0 || dev >= 64) return fail("%s: device index %d is outside the 64 devices the library keeps scratch pointers for", who, dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (err != hipSuccess || !ptr)
+            return fail("%s: hipGetSymbolAddress(scratch) failed on device %d: %s (the first call on a device must not be "
+                        "under stream capture)", who, dev, hipGetErrorString(err));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+size_t cnf_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+int cnf_solve_fwd_static(const CnfNetDesc* net, const float* params, const float* x, const float* logp0, const float* e,
+                         int64_t rows, float t0, float t1, const CnfSolverOpts* opts, float* z_out, float* logp_out,
+                         CnfStats* stats, void* stream) {
+    const char* who = "cnf_solve_fwd_static";
+    if (check_net(net)) return 1;
+    const size_t need = fwd_workspace_need(net);
+    if (need > kStaticScratchBytes)
+        return fail("%s: this solve needs %zu bytes of scratch, the library's static array holds %zu; use cnf_solve_fwd with a "
+                    "workspace of cnf_workspace_bytes()", who, need, kStaticScratchBytes);
+    void* ptr = nullptr;
+    if (static_scratch(who, &ptr)) return 1;
+    return solve_fwd_impl(who, true, net, params, x, logp0, e, rows, t0, t1, opts, z_out, logp_out, ptr, kStaticScratchBytes,
+                          stats, stream);
 }
 
 int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const float* z, const float* e, const float* a_z,

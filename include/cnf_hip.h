@@ -136,6 +136,25 @@ int cnf_solve_fwd(const CnfNetDesc *net, const float *params, const float *x, co
                   float *z_out, float *logp_out, void *workspace, size_t workspace_bytes,
                   CnfStats *stats, void *stream);
 
+/* cnf_solve_fwd for callers that cannot allocate device memory or hand over a workspace: code under HIP graph capture,
+ * tight serving loops (sample_fn / density_fn per request), harnesses that forbid hipMalloc.  NO COUNTERPART IN THE
+ * REFERENCE (whose solver allocates tensors at every Runge-Kutta stage).  Same arguments, results and error behaviour as
+ * cnf_solve_fwd -- bit-identical outputs and stats -- minus `workspace`: the granules of the grid-wide reductions (and, at
+ * hidden width 256, the bf16 pieces of the two hidden matrices) live in a file-scope device array inside the library,
+ * cnf_static_scratch_bytes() = 802 880 bytes per GPU the library has run on, held until the process ends.
+ * The call allocates nothing (no hipMalloc / hipFree, no allocating library routine); it enqueues one memset of the first
+ * 16 448 bytes of that array and the solve kernel(s).  The array's per-device address is looked up on the first call on
+ * each device (hipGetSymbolAddress): make that first call outside stream capture.
+ * Limits: those of cnf_solve_fwd (batch-global control: <= 4096 rows at hidden width 256, <= 16 384 at 64; tile-local and
+ * fixed-grid: any number of rows); a solve whose scratch need exceeds the array is rejected with a message.
+ * Every call on a GPU shares that GPU's array: calls that OVERLAP in time on one device (two streams, two threads) race on
+ * the granules -- serialise them, or give the overlapping solves their own workspaces through cnf_solve_fwd.
+ * CNF_FLAG_CLEAN only spares the memset of `stats` here (the library clears its granules itself).                    */
+size_t cnf_static_scratch_bytes(void);
+int cnf_solve_fwd_static(const CnfNetDesc *net, const float *params, const float *x, const float *logp0,
+                         const float *e, int64_t rows, float t0, float t1, const CnfSolverOpts *opts,
+                         float *z_out, float *logp_out, CnfStats *stats, void *stream);
+
 /* One evaluation of the adjoint's augmented dynamics (the closure `augmented_dynamics` inside
  * OdeintAdjointMethod.backward, a10): given z, a_z, a_logp returns
  *   f, -div, vjp_z = -(a_z . df/dz) + a_logp * d(div)/dz   (rows x dim)
