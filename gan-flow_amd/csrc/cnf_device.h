@@ -161,15 +161,54 @@ struct alignas(16) RedLds {
     int last;   // grid_cleanup: this workgroup took the last ticket
 };
 
+// everything of the net except the two 64x64 matrices: first / last layer weights and the per-layer vectors
+template <int D, class N>
+__device__ inline void stage_net_vectors(N& n, const float* __restrict__ p, int tid, int nthreads = kThreads) {
+    const ParamLayout L = make_layout(D, kH);
+    for (int idx = tid; idx < D * kH; idx += nthreads) {
+        const int m = idx / kH, i = idx % kH;
+        n.w1[m][i] = p[L.w(0) + i * D + m];
+        n.w4[m][i] = p[L.w(3) + m * kH + i];
+    }
+    for (int idx = tid; idx < 3 * kH; idx += nthreads) {
+        const int l = idx / kH, i = idx % kH;
+        n.vec[l][0][i] = p[L.b(l) + i];
+        n.vec[l][1][i] = p[L.hb(l) + i];
+        n.vec[l][2][i] = p[L.wg(l) + i];
+        n.vec[l][3][i] = p[L.bg(l) + i];
+    }
+    if (tid < 16) {
+        const bool in = tid < D;
+        n.vec4[0][tid] = in ? p[L.b(3) + tid] : 0.f;
+        n.vec4[1][tid] = in ? p[L.hb(3) + tid] : 0.f;
+        n.vec4[2][tid] = in ? p[L.wg(3) + tid] : 0.f;
+        n.vec4[3][tid] = in ? p[L.bg(3) + tid] : 0.f;
+    }
+}
+
 template <int D>
 __device__ inline void stage_net(NetLds<D>& n, const float* __restrict__ p, int tid, int nthreads = kThreads) {
     const ParamLayout L = make_layout(D, kH);
     float* img = &n.wimg[0][0][0][0];
-    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += nthreads) {
-        const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
-        const int row = 16 * (tt >> 2) + (lane & 15);
-        const int col = 16 * (tt & 3) + 4 * (lane >> 4) + r;
-        img[idx] = p[L.w(1 + l) + row * kH + col];
+    if (nthreads == kThreads && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        // an image entry is 4 consecutive floats of a weight row: one 16-byte load each (both matrices start at multiples of
+        // 4 floats), and all 8 loads of a thread are in flight before the first store -- the staging of a launch is one
+        // round trip to L2 instead of 32 dependent ones (measured: ~8 us of every solve kernel)
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = tid + kThreads * k, lane = e & 63, tt = (e >> 6) & 15, l = e >> 10;
+            v[k] = *reinterpret_cast<const f32x4*>(&p[L.w(1 + l) + (16 * (tt >> 2) + (lane & 15)) * kH + 16 * (tt & 3) + 4 * (lane >> 4)]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x4*>(&img[4 * (tid + kThreads * k)]) = v[k];
+    } else {
+        for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += nthreads) {
+            const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
+            const int row = 16 * (tt >> 2) + (lane & 15);
+            const int col = 16 * (tt & 3) + 4 * (lane >> 4) + r;
+            img[idx] = p[L.w(1 + l) + row * kH + col];
+        }
     }
     for (int idx = tid; idx < D * kH; idx += nthreads) {
         const int m = idx / kH, i = idx % kH;
@@ -584,12 +623,28 @@ __device__ __forceinline__ void zero_slopes(WS* wl, int n_ws, int tid, int nthre
     }
 }
 
+// x^(1/5) in double for x > 0: single-precision seed (2^(log2(x)/5), ~1e-6 relative), then two Newton steps
+// y <- (4y + x / y^4) / 5, which square the error twice (2e-12, 8e-24): the result is within an ulp or two of the library's
+// pow(x, 0.2) in ~60 instructions instead of several hundred -- every lane of every workgroup executes this once per
+// attempt, on the dependent chain between two Runge-Kutta steps (measured: pow() was ~1.7 us of a ~20 us attempt).
+__device__ __forceinline__ double fifth_root(double x) {
+    double y = (double)__builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf((float)x));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y;
+        y = (4.0 * y + x / (y2 * y2)) * 0.2;
+    }
+    return y;
+}
+
 // step-size update of the controller (Appendix B.5); time bookkeeping is float64 like the original
 __device__ __forceinline__ double next_step_size(double dt, float worst) {
     if (worst == 0.f) return dt * 10.0;
     const double inv_dfactor = worst < 1.f ? 1.0 : 5.0;
     const double root = (double)sqrtf(worst);
-    const double factor = fmax(0.1, fmin(pow(root, 0.2) / 0.9, inv_dfactor));
+    // outside [1e-30, 1e30] the factor is clamped anyway (0.1 below, inv_dfactor above): no need for a root there
+    const double r5 = root < 1e-30 ? 0.0 : (root > 1e30 ? 1e6 : fifth_root(root));
+    const double factor = fmax(0.1, fmin(r5 / 0.9, inv_dfactor));
     return dt / factor;
 }
 
@@ -714,22 +769,30 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
 // Every workgroup takes a ticket after its last reduction; the one that takes the last ticket knows all the others
 // are done reading, clears both banks and resets the ticket (the word right after the banks).  All threads call it.
 constexpr int kGranWords = 2 * kMaxWG * 4;   // 8-byte granules in the two banks; the ticket is granule kGranWords
-__device__ inline void grid_cleanup(GridSync& gs, RedLds& red, int tid) {
+// The ticket is a device-scope atomic whose answer takes ~2 us to come back: grid_ticket() takes it as soon as the
+// workgroup is past its last reduction (before it computes and stores its outputs), grid_cleanup() looks at the answer
+// when everything else is done.  Both are called by all threads; kernels that call only grid_cleanup() get both.
+__device__ inline unsigned grid_ticket(GridSync& gs, int tid) {
+    if (gs.nwg <= 1 || tid != 0) return 0u;
+    unsigned* ticket = reinterpret_cast<unsigned*>(gs.gran + kGranWords);
+    // relaxed: this follows the workgroup's last poll in program order (wave 0 polled, and its loads have returned), and the
+    // granules are only ever written with agent-scope atomic stores that every poller has already seen; an agent-scope
+    // release here would write the whole L2 back at the end of every solve
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void grid_cleanup(GridSync& gs, RedLds& red, int tid, unsigned taken) {
     if (gs.nwg <= 1) return;
     unsigned* ticket = reinterpret_cast<unsigned*>(gs.gran + kGranWords);
-    __syncthreads();
-    if (tid == 0) {
-        // relaxed: the barrier above follows this workgroup's last poll (its loads have returned), and the granules are
-        // only ever written with agent-scope atomic stores that every poller has already seen; an agent-scope release
-        // here would write the whole L2 back at the end of every solve
-        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        red.last = prev == (unsigned)gs.nwg - 1u;
-    }
+    if (tid == 0) red.last = taken == (unsigned)gs.nwg - 1u;
     __syncthreads();
     if (red.last) {
         for (int i = tid; i < 2 * gs.nwg * 4; i += kThreads) gs.gran[i] = 0ull;
         if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+__device__ inline void grid_cleanup(GridSync& gs, RedLds& red, int tid) {
+    __syncthreads();   // wave 0 polls for the workgroup: nobody takes the ticket before it is back from the last reduction
+    grid_cleanup(gs, red, tid, grid_ticket(gs, tid));
 }
 
 // Solver statistics of a batch-global solve: workgroup 0 stores the counters (no atomics, so the block need not be

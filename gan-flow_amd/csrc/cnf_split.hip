@@ -12,6 +12,8 @@
 // Runge-Kutta state (identical arithmetic, bit-identical results), so the controller logic is unchanged.
 // Used when rows <= 16 * 256 (every workgroup resident for the grid-wide reductions); larger batch-global solves
 // fall back to the one-wave-per-tile kernels.
+#include <type_traits>
+
 #include "cnf_split.h"
 #include "cnf_adam.h"
 
@@ -48,8 +50,34 @@ struct alignas(16) SplitXchgB16 {
     uint32_t xb16[2][kNSMaxOf<D>][3][2][64][4];   // [buffer][stream][piece][k-step][lane][tile & 1][2]
     float part[kNW][2 * D][kRows];               // layer-4 partial sums of every wave
 };
-template <class WS, int D>
-__device__ __forceinline__ void gates_into(const NetLds<D>& n, WS& ws, int lane, float t) {
+// The adjoint at d <= 2 runs its four hidden-layer products per evaluation (two forward, two transposed) on the bf16 pipe
+// as well (kBwdB16): forward weight pieces in 48 registers per lane (read from the parameter vector), transposed pieces
+// in a 48 KB LDS image, cotangents published as pieces.  The two 64 x 64 fp32 images (64 KB) are gone from its LDS.
+template <int D>
+constexpr bool kBwdB16 = D <= 2;
+
+template <int D>
+struct alignas(16) NetLdsSmall {   // NetLds without the matrix images
+    float w1[D][kH];
+    float w4[D][kH];
+    float vec[3][4][kH];
+    float vec4[4][16];
+};
+template <int D>
+using BwdNet = typename std::conditional<kBwdB16<D>, NetLdsSmall<D>, NetLds<D>>::type;
+// the adjoint keeps the forward sweep's published activations (xa[l] = input of hidden layer l) until the end of the
+// evaluation -- they are the B operands of that layer's outer products -- so the cotangents get buffers of their own
+template <int D>
+struct alignas(16) SplitXchgBwdB16 {
+    uint32_t xa[2][kNSMaxOf<D>][3][2][64][4];     // [layer][stream][piece][k-step][lane][tile & 1][2]
+    uint32_t xcot[2][kNSMaxOf<D>][3][2][64][4];   // pre-activation cotangents of hidden layer lc
+    float part[kNW][2 * D][kRows];               // layer-4 partial sums of every wave
+};
+template <int D>
+using BwdXchg = typename std::conditional<kBwdB16<D>, SplitXchgBwdB16<D>, SplitXchg<D>>::type;
+
+template <class WS, class N>
+__device__ __forceinline__ void gates_into(const N& n, WS& ws, int lane, float t) {
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
         const float g = sigmoid_f(fmaf(n.vec[l][2][lane], t, n.vec[l][3][lane]));
@@ -70,10 +98,10 @@ __device__ __forceinline__ float sum4(float a, float b, float c, float d) { retu
 // over all evaluations of workgroup 0 / wave 0, printed when the kernel ends.  Compiles to nothing otherwise.
 #ifdef CNF_PROF_CYCLES
 struct Prof {
-    unsigned long long last = 0, acc[20] = {};
+    unsigned long long last = 0, acc[32] = {};
     __device__ __forceinline__ void mark(int i) {
         const unsigned long long now = clock64();
-        acc[i] += now - last;
+        if (last) acc[i] += now - last;
         last = now;
     }
 };
@@ -337,6 +365,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
         ti = t0f + stage_state(stage, dtf, y0, [&](int s, int c) { return ws.kst[s][c][j]; }, yi) * dtf;
     }
 
+    const unsigned taken = grid_ticket(gs, tid);   // all waves are past the last reduction's closing barrier
     if (status == 0) {
         const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
         const float x = (te - ta) / (tb - ta);
@@ -360,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
             a.logp_out[row] = y1[D];
         }
     }
-    grid_cleanup(gs, red, tid);
+    grid_cleanup(gs, red, tid, taken);
     write_stats_global(a.stats, status, nfe, nacc, nrej, nfe, (float)dt, a.rows, tid);
 #ifdef CNF_PROF_SYNC
     if ((blockIdx.x == 0 || blockIdx.x == 77) && tid == 0 && nfe > 100)
@@ -401,13 +430,26 @@ struct SmallIdxS {   // parameters other than the two 64x64 matrices, canonical 
 template <int D>
 constexpr bool kFsalTheta = D <= 2;
 
-template <int D>
-struct alignas(16) SplitBwdLds {
+template <int D, bool B16>
+struct BwdWimgT {
     float wimgT[2][16][64][4];            // as BwdNetLds::wimgT
+};
+template <int D>
+struct BwdWimgT<D, true> {
+    WimgT16 wimgT16;                      // stage_wimgT16 (cnf_split.h)
+};
+template <int D, bool B16>
+struct BwdTransposes {
     float trB[2][kNSMaxOf<D>][kH * kRows];     // transposed layer inputs, all 64 features: [buffer][stream][feature*16 + pos(row)]
     float trA[kNW][kNSMaxOf<D>][16 * kRows];   // per wave: transposed, weighted cotangents of its own 16 features
-    float small[kFsalTheta<D> ? 3 : 1][SmallIdxS<D>::padded];   // d/dtheta of the small parameters (waves own disjoint
-                                          // features): [0] the step's weighted sum, [1], [2] the FSAL buffers
+};
+template <int D>
+struct BwdTransposes<D, true> {};              // kBwdB16: operands are read transposed from the piece buffers (outer_b16)
+template <int D>
+struct alignas(16) SplitBwdLds : BwdWimgT<D, kBwdB16<D>>, BwdTransposes<D, kBwdB16<D>> {
+    float small[kFsalTheta<D> ? 4 : 1][SmallIdxS<D>::padded];   // d/dtheta of the small parameters (waves own disjoint
+                                          // features): [0] the step's weighted sum, [1], [2] the FSAL buffers, [3] the
+                                          // running total over accepted steps (two-workgroups-per-tile launches)
     float part2[kNW][D][kRows];           // vjp_z partial sums of every wave
     float wq[8];                          // quadrature weights of the current attempt
 };
@@ -424,12 +466,30 @@ constexpr bool kExpDw = false;
 constexpr bool kExpDw = true;
 #endif
 
+// the adjoint kernels' weights: fp32 images of W and W^T in LDS, or (kBwdB16) register pieces of W + an LDS image of W^T pieces
+template <int D>
+__device__ __forceinline__ void stage_bwd_net(BwdNet<D>& net, SplitBwdLds<D>& sb, SplitWeightsB16& wb, const float* __restrict__ p, int tid) {
+    if constexpr (kBwdB16<D>) {
+        stage_net_vectors<D>(net, p, tid);
+        stage_wimgT16<D>(sb.wimgT16, p, tid);
+        load_weights_b16_global<D>(wb, p, tid >> 6, tid & 63);
+    } else {
+        stage_net(net, p, tid);
+        stage_wimgT<D>(&sb.wimgT[0][0][0][0], p, tid);
+    }
+}
+
 // one augmented evaluation; same mathematics as aug_eval (cnf_bwd.hip), each wave on its own feature tile
-template <int D, bool HUTCH, class WS>
-__device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D>& sb, WS& ws, SplitXchg<D>& xc, int lane,
+// acc / alt: the accumulators of the hidden matrices' outer products; to_alt (uniform) sends this evaluation's to `alt`
+// (the FSAL buffer), so that no register block has to be copied around the call.
+template <int D, bool HUTCH, class WS, int NL>
+__device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWeightsB16& wb, SplitBwdLds<D>& sb, WS& ws,
+                                               BwdXchg<D>& xc, int lane,
                                                int wave, float t, const float (&z)[D], const float (&e)[D],
                                                const float (&az)[D], float al, float w, bool with_theta, float (&f)[D],
-                                               float& div, float (&vz)[D], BigAccS& acc, int small_base, int part = 0) {
+                                               float& div, float (&vz)[D], BigAccT<NL>& acc, BigAccT<NL>& alt, bool to_alt,
+                                               int small_base, int part, Prof& pr) {
+    constexpr bool B16 = kBwdB16<D>;
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     using SI = SmallIdxS<D>;
@@ -441,6 +501,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
     const int fo = 16 * wave + 4 * q;
     const int pos = (j & 3) * 4 + (j >> 2);
     gates_into(n, ws, lane, t);
+    pr.mark(1);
     // after reduce8 lane j owns index r* = j & 3 and parameter kind j >> 2 (bias, hyper-bias, gate weight, gate bias):
     // factor = k0 * g + k1 * t + gg * (k2 * t + k3) as arithmetic on lane masks (nested selects compile to branches)
     const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0;
@@ -477,24 +538,33 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
             }
         }
     }
+    pr.mark(2);
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
-        __syncthreads();
         f32x4 a4[NS];
+        if constexpr (B16) {
+            publish_b16<NS>(xc.xa[l], act, wave, lane);
+            __syncthreads();
+            pr.mark(3 + 3 * l);
+            hidden_b16<NS>(xc.xa[l], wb, l, lane, a4);
+            pr.mark(4 + 3 * l);
+        } else {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) a4[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
+            __syncthreads();
 #pragma unroll
-        for (int Ti = 0; Ti < 4; ++Ti) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&n.wimg[l][wave * 4 + Ti][lane][0]);
-            f32x4 in[NS];
+            for (int s = 0; s < NS; ++s) a4[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
+            for (int Ti = 0; Ti < 4; ++Ti) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&n.wimg[l][wave * 4 + Ti][lane][0]);
+                f32x4 in[NS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) a4[s] = mfma16(a[r], in[s][r], a4[s]);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) a4[s] = mfma16(a[r], in[s][r], a4[s]);
+            }
         }
         const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
         const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
@@ -512,6 +582,7 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 act[s][r] = dg * a4[s][r];
             }
         }
+        pr.mark(5 + 3 * l);
     }
     f32x4 w4[D];
 #pragma unroll
@@ -530,7 +601,9 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
             xc.part[wave][D + m][j] = pd;
         }
     }
+    pr.mark(9);
     __syncthreads();
+    pr.mark(10);
     float g4[D], u4[D], U4[D];
     div = 0.f;
 #pragma unroll
@@ -595,21 +668,43 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
         }
     }
 
+    pr.mark(12);
     // dW[16*wave + i'][:] += sum_rows (w ubar)[i'][row] * x_in[:][row] of hidden layer lc (K = the 16 rows).  Nothing on
     // the evaluation's critical path depends on these 96 MFMAs, so they are issued one layer LATE, next to the
     // reductions and gate arithmetic of the following layer: matrix pipe and vector ALU overlap.
+    auto issue_dw_into = [&](BigAccT<NL>& dst, int lc) {
+        if constexpr (!B16) {
+            const int buf = 1 - lc;
+            const int li = NL == 1 ? 0 : lc;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.trA[wave][s][j * kRows + 4 * q]);
+                f32x4 b4[4];
+#pragma unroll
+                for (int T = 0; T < 4; ++T) b4[T] = *reinterpret_cast<const f32x4*>(&sb.trB[buf][s][(16 * T + j) * kRows + 4 * q]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int Ti = 0; Ti < 4; ++Ti) dst.gw[li][Ti] = mfma16(a4[ks], b4[Ti][ks], dst.gw[li][Ti]);
+            }
+        }
+    };
     auto issue_dw = [&](int lc) {
-        const int buf = 1 - lc;
+        if constexpr (B16) {
+            // unweighted outer products of this evaluation on the bf16 pipe, then one fused multiply-add per register
+            f32x4 tmp[4];
+            outer_b16<NS>(xc.xcot[lc], xc.xa[lc], wave, lane, tmp);
+            const int li = NL == 1 ? 0 : lc;
+            if (to_alt) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.trA[wave][s][j * kRows + 4 * q]);
-            f32x4 b4[4];
+                for (int Ti = 0; Ti < 4; ++Ti) alt.gw[li][Ti] += w * tmp[Ti];
+            } else {
 #pragma unroll
-            for (int T = 0; T < 4; ++T) b4[T] = *reinterpret_cast<const f32x4*>(&sb.trB[buf][s][(16 * T + j) * kRows + 4 * q]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int Ti = 0; Ti < 4; ++Ti) acc.gw[lc][Ti] = mfma16(a4[ks], b4[Ti][ks], acc.gw[lc][Ti]);
+                for (int Ti = 0; Ti < 4; ++Ti) acc.gw[li][Ti] += w * tmp[Ti];
+            }
+        } else {
+            if (to_alt) issue_dw_into(alt, lc);
+            else issue_dw_into(acc, lc);
         }
     };
 
@@ -658,12 +753,17 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
             const float fac = fmaf(gg, km23, fmaf(km0, gs, km1t));
             lds_add(&small[SI::vec(L) + kind * kH + fo + qq], w * fac * (kind < 2 ? st : gt));
         }
+        pr.mark(l == 1 ? 13 : (l == 0 ? 16 : 19));
         if (l >= 0) {
             const int lc = l < 0 ? 0 : l;
             const int buf = 1 - lc;   // layer 3 publishes through buffer 0, layer 2 through buffer 1
+            if constexpr (B16) {
+                publish_b16<NS>(xc.xcot[lc], cot, wave, lane);
+            } else {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
-            if ((lc == 1 ? th_hi : th_lo) && kExpDw) {
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
+            }
+            if constexpr (!B16) if ((lc == 1 ? th_hi : th_lo) && kExpDw) {
                 const f32x4 gi = *reinterpret_cast<const f32x4*>(&ws.gate[L - 1][0][fo]);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -692,23 +792,29 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
                 }
             }
             __syncthreads();
+            pr.mark(l == 1 ? 14 : 17);
             // cotangent of this layer's input, own input-feature tile: (W^T ubar)[16*wave ..]
             f32x4 o4[NS];
+            if constexpr (B16) {
+                hidden_b16_lds<NS>(xc.xcot[lc], sb.wimgT16[lc][wave], lane, o4);
+            } else {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) o4[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < NS; ++s) o4[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int To = 0; To < 4; ++To) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&sb.wimgT[lc][wave * 4 + To][lane][0]);
-                f32x4 in[NS];
+                for (int To = 0; To < 4; ++To) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&sb.wimgT[lc][wave * 4 + To][lane][0]);
+                    f32x4 in[NS];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[buf][s][To][lane][0]);
+                    for (int s = 0; s < NS; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[buf][s][To][lane][0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) o4[s] = mfma16(a[r], in[s][r], o4[s]);
+                        for (int s = 0; s < NS; ++s) o4[s] = mfma16(a[r], in[s][r], o4[s]);
+                }
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) cot[s] = o4[s];
+            pr.mark(l == 1 ? 15 : 18);
         } else {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
@@ -737,8 +843,39 @@ __device__ __forceinline__ void aug_eval_split(const NetLds<D>& n, SplitBwdLds<D
 #pragma unroll
             for (int m = 0; m < D; ++m)
                 vz[m] = sum4(sb.part2[0][m][j], sb.part2[1][m][j], sb.part2[2][m][j], sb.part2[3][m][j]);
+            pr.mark(11);
         }
     }
+}
+
+// Two-workgroups-per-tile launches keep running totals over the accepted steps -- the matrix in 16 registers, the small
+// parameters in sb.small[3] -- and store their slab ONCE when the solve ends: no global read-modify-write between steps.
+template <int D>
+__device__ inline void commit_total(SplitBwdLds<D>& sb, BigAccT<1>& tot, const BigAccT<1>& acc, const BigAccT<1>& gfirst,
+                                    const BigAccT<1>& glast, int i_first, int i_last, float w_first, float w_last, int tid, int part) {
+    const int i_lo = part == 1 ? SmallIdxS<D>::v3 : 0, i_hi = part == 2 ? SmallIdxS<D>::v3 : SmallIdxS<D>::count;
+    __syncthreads();
+    for (int i = i_lo + tid; i < i_hi; i += kThreads)
+        sb.small[3][i] += fmaf(w_last, sb.small[i_last][i], fmaf(w_first, sb.small[i_first][i], sb.small[0][i]));
+#pragma unroll
+    for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            tot.gw[0][Ti][r] += fmaf(w_last, glast.gw[0][Ti][r], fmaf(w_first, gfirst.gw[0][Ti][r], acc.gw[0][Ti][r]));
+    __syncthreads();
+}
+template <int D>
+__device__ inline void store_total(const SplitBwdLds<D>& sb, const BigAccT<1>& tot, float* __restrict__ slab_wg, int tid, int part) {
+    const ParamLayout L = make_layout(D, kH);
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int i_lo = part == 1 ? SmallIdxS<D>::v3 : 0, i_hi = part == 2 ? SmallIdxS<D>::v3 : SmallIdxS<D>::count;
+    __syncthreads();
+    for (int i = i_lo + tid; i < i_hi; i += kThreads) slab_wg[SmallIdxS<D>::canonical(i)] = sb.small[3][i];
+    const int l = 2 - part;   // part 1 keeps W3 (layer index 1 of the two hidden matrices), part 2 keeps W2
+#pragma unroll
+    for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] = tot.gw[0][Ti][r];
 }
 
 template <int D>
@@ -801,13 +938,13 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
                                                              float* __restrict__ vz_out) {
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int C = 2 * D + 1;
-    __shared__ NetLds<D> net;
+    __shared__ BwdNet<D> net;
     __shared__ SplitBwdLds<D> sb;
     __shared__ SplitWaveLds<C> wl[kShareWaveLds<D> ? 1 : kNW];
-    __shared__ SplitXchg<D> xc;
+    __shared__ BwdXchg<D> xc;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
-    stage_net(net, a.params, tid);
-    stage_wimgT<D>(&sb.wimgT[0][0][0][0], a.params, tid);
+    SplitWeightsB16 wb;
+    stage_bwd_net<D>(net, sb, wb, a.params, tid);
     for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) sb.small[0][i] = 0.f;
     __syncthreads();
     const long row = (long)blockIdx.x * kRows + j;
@@ -823,7 +960,8 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     const float al = valid ? a_l[rr] : 0.f;
     BigAccS acc;
     acc.zero();
-    aug_eval_split<D, HUTCH>(net, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc, 0);
+    Prof pr;
+    aug_eval_split<D, HUTCH>(net, wb, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc, acc, false, 0, 0, pr);
     #pragma unroll
     for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
         f[m] = fmaf(-res, zz[m], f[m]);
@@ -841,20 +979,24 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     commit_step_split<D>(sb, acc, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, tid);
 }
 
-template <int D, bool HUTCH>
+// RUNTOT: the launch has two workgroups per tile (a.spread) and each keeps ONE matrix: accumulators of 16 registers, so
+// a fourth one -- the running total over accepted steps -- fits, and the slab is stored once at the end (commit_total).
+template <int D, bool HUTCH, bool RUNTOT>
 __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a) {
+    static_assert(!RUNTOT || kFsalTheta<D>, "running totals are built for the FSAL kernels (d <= 2)");
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int C = 2 * D + 1;
     constexpr int CE = D + 1;
-    __shared__ NetLds<D> net;
+    constexpr int NL = RUNTOT ? 1 : 2;
+    __shared__ BwdNet<D> net;
     __shared__ SplitBwdLds<D> sb;
     __shared__ SplitWaveLds<C> wl[kShareWaveLds<D> ? 1 : kNW];
-    __shared__ SplitXchg<D> xc;
+    __shared__ BwdXchg<D> xc;
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
-    stage_net(net, a.params, tid);
-    stage_wimgT<D>(&sb.wimgT[0][0][0][0], a.params, tid);
+    SplitWeightsB16 wb;
+    stage_bwd_net<D>(net, sb, wb, a.params, tid);
     zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid);
     for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += kThreads) (&sb.small[0][0])[i] = 0.f;
     __syncthreads();
@@ -906,11 +1048,15 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[CE];
     constexpr bool FSAL = kFsalTheta<D>;
-    BigAccS acc, gfirst, glast;   // acc: the working accumulator of aug_eval_split; gfirst / glast: see kFsalTheta
+    BigAccT<NL> acc, gfirst, glast, total;   // acc: the attempt's weighted sums; gfirst / glast: see kFsalTheta; total: RUNTOT
     acc.zero();
     gfirst.zero();
     glast.zero();
+    total.zero();
     int i_first = 1, i_last = 2;  // which of sb.small[1], sb.small[2] holds the first / seventh stage's sums
+    float wq[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // quadrature weights of the current attempt (every lane holds all seven)
+    Prof pr;
+    pr.mark(0);
 
     if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
     for (; status == 0;) {
@@ -924,28 +1070,26 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         // which d/dtheta sum this evaluation feeds: the step's weighted quadrature, or (FSAL) an unweighted buffer
         const bool to_first = FSAL && phase == PH_F0;
         const bool to_last = FSAL && phase == PH_STAGE && stage == 6;
-        const float wst = (to_first || to_last) ? 1.f : (phase == PH_STAGE ? sb.wq[stage] : 0.f);
+        float wsel = wq[0];
+#pragma unroll
+        for (int s_ = 1; s_ < 7; ++s_) wsel = stage == s_ ? wq[s_] : wsel;
+        const float wst = (to_first || to_last) ? 1.f : (phase == PH_STAGE ? wsel : 0.f);
         const bool with_theta = wst != 0.f;
-        int small = 0;
-        BigAccS keep;
-        if (FSAL && (to_first || to_last)) {
-            small = (to_first ? i_first : i_last) * SmallIdxS<D>::padded;
-            keep = acc;
-            acc.zero();
-        }
-        aug_eval_split<D, HUTCH>(net, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc, small, part);
+        // FSAL evaluations accumulate into glast (zero at that point: start of the solve / start of the attempt)
+        const bool to_alt = FSAL && (to_first || to_last);
+        const int small = to_alt ? (to_first ? i_first : i_last) * SmallIdxS<D>::padded : 0;
+        pr.mark(0);
+        aug_eval_split<D, HUTCH>(net, wb, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc, glast,
+                                 to_alt, small, part, pr);
         #pragma unroll
         for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
             f[m] = fmaf(-res, zz[m], f[m]);
             vz[m] = fmaf(res, az[m], vz[m]);
         }
         div -= res * (float)D;
-        if (FSAL && (to_first || to_last)) {
-            if (to_first) gfirst = acc;
-            else glast = acc;
-            acc = keep;
-        }
+        if (to_first) gfirst = glast;   // once per solve; the restart below clears glast
         ++nrun;
+        pr.mark(20);
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             k[m] = sgn * f[m];
@@ -1022,13 +1166,16 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                         if (!isfinite(y0[c])) S[2] += 1.0;
                     }
                 }
+                pr.mark(21);
                 if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                pr.mark(22);
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
                 const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
                 const bool accept = (rz <= 1.f) && (rl <= 1.f);
                 if (accept) {
                     ++nacc;
-                    if (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid, nacc == 1, part);
+                    if constexpr (RUNTOT) commit_total<D>(sb, total, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], tid, part);
+                    else if constexpr (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], slab, tid, nacc == 1, part);
                     else commit_step_split<D>(sb, acc, slab, tid, nacc == 1, part);
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
@@ -1045,8 +1192,10 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                 } else {
                     ++nrej;
                 }
+                pr.mark(23);
                 dt = next_step_size(dt, pymax(rz, rl));
                 restart = true;
+                pr.mark(24);
             }
         }
         if (restart) {
@@ -1057,29 +1206,39 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             stage = FSAL ? 1 : 0;
             phase = PH_STAGE;
             acc.zero();
-            __syncthreads();   // every wave is past its last read of small / wq of the previous attempt
+            if (FSAL) glast.zero();
+            __syncthreads();   // every wave is past its last read of small of the previous attempt
             for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) {
                 sb.small[0][i] = 0.f;
                 if (FSAL) sb.small[i_last][i] = 0.f;
             }
-            if (tid < 7) {
-                const int s = tid;
-                float v;
+            // quadrature weights of the attempt: dt b_s, or on the step that passes the end time the dense-output weights
+            // (tableau entries as literals; every lane computes all seven: no table loads, no LDS hand-off)
+            {
+                constexpr float kB[7] = {(float)(35.0 / 384), 0.f, (float)(500.0 / 1113), (float)(125.0 / 192), (float)(-2187.0 / 6784),
+                                         (float)(11.0 / 84), 0.f};
+                constexpr float kM[7] = {(float)(6025192743.0 / 30085553152.0 / 2), 0.f, (float)(51252292925.0 / 65400821598.0 / 2),
+                                         (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
+                                         (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
                 if (tau_end > tau + dt) {
-                    v = s < 6 ? dtf * kBeta[5][s] : 0.f;
+#pragma unroll
+                    for (int s_ = 0; s_ < 7; ++s_) wq[s_] = s_ < 6 ? dtf * kB[s_] : 0.f;
                 } else {
                     const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
                     const float x = (te - ta) / (tb - ta);
                     const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
-                    const float b = s < 6 ? kBeta[5][s] : 0.f;
-                    const float cm = kCMid[s];
-                    v = dtf * (x4 * (-8.f * b + 16.f * cm) + x3 * (14.f * b - 32.f * cm) + x2 * (-5.f * b + 16.f * cm));
-                    if (s == 0) v += dtf * (-2.f * x4 + 5.f * x3 - 4.f * x2 + x);
-                    if (s == 6) v += dtf * (2.f * x4 - 3.f * x3 + x2);
+#pragma unroll
+                    for (int s_ = 0; s_ < 7; ++s_) {
+                        const float b = kB[s_], cm = kM[s_];
+                        float v = dtf * (x4 * (-8.f * b + 16.f * cm) + x3 * (14.f * b - 32.f * cm) + x2 * (-5.f * b + 16.f * cm));
+                        if (s_ == 0) v += dtf * (-2.f * x4 + 5.f * x3 - 4.f * x2 + x);
+                        if (s_ == 6) v += dtf * (2.f * x4 - 3.f * x3 + x2);
+                        wq[s_] = v;
+                    }
                 }
-                sb.wq[s] = v;
             }
             __syncthreads();
+            pr.mark(25);
         }
         if (stage == 0) {
             ti = t0f;
@@ -1088,8 +1247,10 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         } else {
             ti = t0f + stage_state(stage, dtf, y0, [&](int s, int c) { return ws.kst[s][c][j]; }, yi) * dtf;
         }
+        pr.mark(26);
     }
 
+    const unsigned taken = grid_ticket(gs, tid);   // all waves are past the last reduction's closing barrier
     if (status == 0) {
         const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
         const float x = (te - ta) / (tb - ta);
@@ -1111,8 +1272,24 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         }
         if (counted) a.grad_logp0[row] = al;
     }
-    grid_cleanup(gs, red, tid);
+    if constexpr (RUNTOT) store_total<D>(sb, total, slab, tid, part);
+    grid_cleanup(gs, red, tid, taken);
     write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
+#ifdef CNF_PROF_CYCLES
+    if ((blockIdx.x == 0 || blockIdx.x == 1) && (tid == 0 || tid == 128) && nrun > 100) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 32; ++i) tot += pr.acc[i];
+        const double n = nrun;
+        printf("bwd prof wg %d wave %d evals %d cycles/eval total %.0f: rk %.0f gates %.0f L1 %.0f | pub0 %.0f mm0 %.0f act0 %.0f | pub1 %.0f mm1 %.0f "
+               "act1 %.0f | L4part %.0f bar %.0f | revhead %.0f | r3vec %.0f r3pub %.0f r3mm %.0f | r2vec %.0f r2pub %.0f r2mm %.0f | r1vec %.0f r1end %.0f\n",
+               (int)blockIdx.x, tid >> 6, nrun, tot / n, pr.acc[0] / n, pr.acc[1] / n, pr.acc[2] / n, pr.acc[3] / n, pr.acc[4] / n, pr.acc[5] / n,
+               pr.acc[6] / n, pr.acc[7] / n, pr.acc[8] / n, pr.acc[9] / n, pr.acc[10] / n, pr.acc[12] / n, pr.acc[13] / n, pr.acc[14] / n,
+               pr.acc[15] / n, pr.acc[16] / n, pr.acc[17] / n, pr.acc[18] / n, pr.acc[19] / n, pr.acc[11] / n);
+        printf("bwd prof wg %d wave %d between evaluations, cycles/eval: k+kst %.0f errest %.0f reduce %.0f decide+commit %.0f next_dt %.0f restart %.0f "
+               "stage_state %.0f looptop %.0f\n", (int)blockIdx.x, tid >> 6, pr.acc[20] / n, pr.acc[21] / n, pr.acc[22] / n, pr.acc[23] / n,
+               pr.acc[24] / n, pr.acc[25] / n, pr.acc[26] / n, pr.acc[0] / n);
+    }
+#endif
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------
@@ -1238,7 +1415,12 @@ template <int D, bool HUTCH>
 static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
     dbg_timing_begin(s);
-    hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH>), dim3(a.spread ? 2 * grid : grid), dim3(kThreads), 0, s, a);
+    if constexpr (kFsalTheta<D>) {
+        if (a.spread) hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH, true>), dim3(2 * grid), dim3(kThreads), 0, s, a);
+        else hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH, false>), dim3(a.spread ? 2 * grid : grid), dim3(kThreads), 0, s, a);
+    }
     dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
