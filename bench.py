@@ -52,7 +52,7 @@ def parse():
                    help="comma list of the additional measurements to run: roofline, late, eval, d16, wide, pair, cpu, config1, "
                         "repeats ('' = none)")
     p.add_argument("--repeats", type=int, default=5, help="extra repeats of the timed loop (fresh seed-1 model each) for the spread keys")
-    p.add_argument("--cpu-late-iters", type=int, default=1,
+    p.add_argument("--cpu-late-iters", type=int, default=2,
                    help="CPU-oracle iterations on the late_training field (tens of seconds each; 0 = skip)")
     p.add_argument("--config1-cpu-iters", type=int, default=100, help="CPU-oracle iterations of BASELINE config 1 (gu_num=1)")
     p.add_argument("--dry-run", action="store_true",
@@ -185,24 +185,32 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.item()
 
+    def fused_run(batches_):
+        """W warm-up iterations (real steps, then the graph capture), then exactly K timed iterations of a fresh seeded model:
+        (model, seconds [max over ranks], (nfe_forward, nfe_backward) of the last iteration)."""
+        torch.manual_seed(1 + rank)
+        model_ = gu_ffjord.build_model(2).to(dev).train()
+        # library kernels only: forward solve, adjoint solve (loss + cotangents inside), slab sum + Adam
+        step_ = gu_ffjord.FusedTrainStep(model_, batches_[0], lr=1e-3, weight_decay=1e-5, graph=True, spread=spread,
+                                         warmup_batches=batches_[:max(1, args.warmup)])
+        barrier()
+        t0_ = time.perf_counter()
+        for x_ in batches_[args.warmup:]:
+            step_(x_)
+        barrier()
+        el_ = max_over_ranks(time.perf_counter() - t0_)
+        return model_, el_, step_.check()
+
     # ---------------------------------------------------------------- headline: training iterations/s
     data = make_gu(8, device="cpu", seed=1 + rank, extend_dim=True)
     batches = [data.get_sample(args.batch).to(dev) for _ in range(args.warmup + args.steps)]
-    torch.manual_seed(1 + rank)
-    model = gu_ffjord.build_model(2).to(dev).train()
     graphed = None
     if args.mode == "fused":
-        # library kernels only: forward solve, loss + gradient, adjoint solve, Adam; warm-up iterations are real steps
-        graphed = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=True, spread=spread,
-                                           warmup_batches=batches[:max(1, args.warmup)])
-        barrier()
-        t0 = time.perf_counter()
-        for x in batches[args.warmup:]:
-            graphed(x)
-        barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
-        nfe_f, nfe_b = [args.steps * v for v in graphed.check()]     # NFE of the last iteration (device-side words)
+        model, elapsed, last_nfe = fused_run(batches)
+        nfe_f, nfe_b = [args.steps * v for v in last_nfe]     # NFE of the last iteration (device-side words)
     elif args.mode == "graph":
+        torch.manual_seed(1 + rank)
+        model = gu_ffjord.build_model(2).to(dev).train()
         # the autograd loop as one hipGraph replay (gu_ffjord.GraphedTrainStep); warm-up iterations run eagerly
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
         graphed = gu_ffjord.GraphedTrainStep(model, opt, batches[0], batches[:max(1, args.warmup)])
@@ -217,6 +225,8 @@ def main():
         for blk in model.chain:
             blk.sync_stats = True
     else:
+        torch.manual_seed(1 + rank)
+        model = gu_ffjord.build_model(2).to(dev).train()
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
         for x in batches[:args.warmup]:
             train_step(model, opt, x, gu_ffjord)
@@ -246,13 +256,22 @@ def main():
 
     extras = set(e for e in args.extras.split(",") if e)
     ctx = dict(args=args, world=world, rank=rank, dev=dev, batches=batches, model=model, barrier=barrier, spread=spread,
-               max_over_ranks=max_over_ranks)
-    if "roofline" in extras and rank == 0:
-        out["roofline"] = measure_roofline(ctx)
+               max_over_ranks=max_over_ranks, fused_run=fused_run)
     if "pair" in extras:
         # first: whether two streams of one process overlap depends on how many streams / graphs the process has used
         # so far (ROCm multiplexes streams onto 4 hardware queues); after the measurements below they no longer do
         out["two_trials_per_gpu"] = measure_pair(ctx)
+    if "repeats" in extras and args.mode == "fused" and args.repeats > 0:
+        # the timed region is K x ~0.2 ms: one scheduler hiccup away from a wrong number.  The same W + K loop again, from
+        # the same seed and batches (identical work), `repeats` more times; `value` above stays the first run's.
+        ms = sorted(1e3 * fused_run(batches)[1] / args.steps for _ in range(args.repeats))
+        out["repeats"] = {"n": len(ms), "ms_per_step_min": round(ms[0], 4), "ms_per_step_median": round(ms[len(ms) // 2], 4),
+                          "ms_per_step_max": round(ms[-1], 4), "value_at_median": round(world * 1e3 / ms[len(ms) // 2], 1),
+                          "note": "same W warm-up + K timed iterations repeated from the same seed and batches; `value` is the first run"}
+    if "config1" in extras:
+        out["config1"] = measure_config1(ctx)
+    if "roofline" in extras and rank == 0:
+        out["roofline"] = measure_roofline(ctx)
     if "late" in extras:
         out["late_training"] = measure_late(ctx)
     if "eval" in extras:
@@ -271,46 +290,18 @@ def main():
 
 
 def measure_roofline(ctx):
-    """Dominant kernel = the adjoint solve.  achieved = algorithmic FLOP per launch (rows x NFE x 3 x F_eval, NFE as the
-    reference counts it; the state work a CNF_FLAG_SPREAD launch does twice is counted once) / mean launch duration, HIP
-    events on the launch stream (torch's current stream)."""
-    from gan_flow_amd import _native
-    args, model, batches = ctx["args"], ctx["model"], ctx["batches"]
-    blk = model.chain[0]
-    fn = blk.odefunc.odefunc
-    net = fn.net_desc()
-    params = fn.diffeq.flat_parameters().detach()
-    opts = _native.make_opts("dopri5", blk.rtol, blk.atol, flags=_native.FLAG_SPREAD if ctx["spread"] else 0)   # as the timed step launches it
-    T = float(blk.sqrt_end_time.detach() ** 2)
-    x = batches[-1]
-    z1, l1, _ = _native.solve_fwd(net, params, x, None, 0.0, T, opts)
-    gz, gl = z1 / args.batch, torch.full_like(l1, 1.0 / args.batch)
-    reps = 20
-    # kernel-only duration: the library records HIP events on the launch stream right around the solve kernel
-    # (cnf_debug_kernel_timing); the whole call (memset of the slabs + kernel + slab reduction) is bracketed as well
-    _native.kernel_timing(True)
-    ms = call_ms = 0.0
-    for _ in range(reps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        st = _native.solve_bwd(net, params, z1, l1, gz, gl, 0.0, T, opts)[3]
-        b.record()
-        ms += _native.last_kernel_ms() / reps
-        torch.cuda.synchronize()
-        call_ms += a.elapsed_time(b) / reps
-    _native.kernel_timing(False)
-    st = _native.Stats(st)
-    flops = args.batch * st.nfe * 3 * F_EVAL_D2
-    achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None   # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/): not measurable in-process
+    """Dominant kernel = the adjoint solve of the timed step (seed-1 init, NFE 14).  `traffic`: HBM bytes per launch from the
+    separate rocprofv3 --pmc passes of this round (profiles/), not measurable in-process."""
+    args = ctx["args"]
+    res = adjoint_roofline(ctx["model"], ctx["batches"][-1], ctx["spread"])
+    traffic = None
     import glob
     tpath = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bwd_traffic.json"))) or [""])[-1]   # the latest round's passes
     if os.path.exists(tpath) and args.batch == 2048:
         with open(tpath) as fh:
             traffic = json.load(fh)["hbm_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "dopri5_bwd_split_kernel<2,false>", "achieved": round(achieved, 4),
-            "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5),
-            "traffic": traffic, "launch_ms": round(ms, 4), "call_ms": round(call_ms, 4), "nfe": st.nfe, "evals_run": st.evals_run, "flop_per_launch": flops}
+    res["traffic"] = traffic
+    return res
 
 
 def measure_late(ctx):
@@ -331,9 +322,113 @@ def measure_late(ctx):
         lb += b
     ctx["barrier"]()
     lel = ctx["max_over_ranks"](time.perf_counter() - t0)
-    return {"value": round(world * args.late_steps / lel, 4), "unit": "iters/s", "ms_per_step": round(1e3 * lel / args.late_steps, 2),
-            "mean_nfe_forward": round(lf / args.late_steps, 1), "mean_nfe_backward": round(lb / args.late_steps, 1),
-            "workload": "same step on the reference's trained gu_num=8 field (checkpoint weights embedded in d=2)"}
+    res = {"value": round(world * args.late_steps / lel, 4), "unit": "iters/s", "ms_per_step": round(1e3 * lel / args.late_steps, 2),
+           "mean_nfe_forward": round(lf / args.late_steps, 1), "mean_nfe_backward": round(lb / args.late_steps, 1),
+           "workload": "same step on the reference's trained gu_num=8 field (checkpoint weights embedded in d=2)"}
+    if rank == 0:
+        res["roofline"] = adjoint_roofline(late, batches[1], ctx["spread"], reps=3)
+        if world == 1 and args.cpu_late_iters > 0 and "cpu" in set(args.extras.split(",")):
+            # the CPU oracle on the same field and batches: where BASELINE config 2 spends > 99 % of its iterations
+            import oracle
+            ncores = min(16, os.cpu_count() or 1)
+            torch.set_num_threads(ncores)
+            torch.manual_seed(1)
+            om = embed_trained_multimodal(oracle.build_cnf(2)).train()
+            oopt = torch.optim.Adam(om.parameters(), lr=1e-5, weight_decay=1e-5)
+            t0 = time.perf_counter()
+            for i in range(args.cpu_late_iters):
+                xb = batches[1 + i].cpu()
+                oopt.zero_grad(set_to_none=True)
+                z, dl = om(xb, torch.zeros(xb.shape[0], 1))
+                (-(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()).backward()
+                oopt.step()
+            cel = time.perf_counter() - t0
+            st = om.chain[0].stats
+            res["cpu_baseline"] = {"value": round(args.cpu_late_iters / cel, 5), "unit": "iters/s", "cores": ncores, "kind": "port",
+                                   "sample": "%d training iteration(s) of the PyTorch-CPU oracle on the same field and batch "
+                                             "(%.1f s; forward %d + %d attempts, adjoint %d + %d), torch.set_num_threads(%d)"
+                                             % (args.cpu_late_iters, cel, st["forward"]["n_accepted"], st["forward"]["n_rejected"],
+                                                st["backward"]["n_accepted"], st["backward"]["n_rejected"], ncores)}
+            res["vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    return res
+
+
+def adjoint_roofline(model, x, spread, reps=20):
+    """The adjoint solve kernel of `model` on batch `x`: algorithmic FLOP per launch (rows x NFE x 3 x F_eval, NFE as the reference
+    counts it; the state work a two-workgroups-per-tile launch does twice is counted once) / mean kernel duration, measured
+    with HIP events recorded by the library on the launch stream right around the kernel (cnf_debug_kernel_timing)."""
+    from gan_flow_amd import _native
+    blk = model.chain[0]
+    fn = blk.odefunc.odefunc
+    net = fn.net_desc()
+    params = fn.diffeq.flat_parameters().detach()
+    opts = _native.make_opts("dopri5", blk.rtol, blk.atol, flags=_native.FLAG_SPREAD if spread else 0)   # as the timed step launches it
+    T = float(blk.sqrt_end_time.detach() ** 2)
+    rows = x.shape[0]
+    z1, l1, _ = _native.solve_fwd(net, params, x, None, 0.0, T, opts)
+    gz, gl = z1 / rows, torch.full_like(l1, 1.0 / rows)
+    _native.solve_bwd(net, params, z1, l1, gz, gl, 0.0, T, opts)
+    _native.kernel_timing(True)
+    ms = call_ms = 0.0
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        st = _native.solve_bwd(net, params, z1, l1, gz, gl, 0.0, T, opts)[3]
+        b.record()
+        ms += _native.last_kernel_ms() / reps
+        torch.cuda.synchronize()
+        call_ms += a.elapsed_time(b) / reps
+    _native.kernel_timing(False)
+    st = _native.Stats(st)
+    flops = rows * st.nfe * 3 * F_EVAL_D2
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "dopri5_bwd_split_kernel<2,false,%s>" % ("true" if spread else "false"),
+            "achieved": round(achieved, 4), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5), "launch_ms": round(ms, 4), "call_ms": round(call_ms, 4),
+            "nfe": st.nfe, "evals_run": st.evals_run, "us_per_evaluation": round(1e3 * ms / st.evals_run, 3),
+            "flop_per_launch": flops,
+            "peak_note": "dense fp32 matrix peak (the hidden-layer products run on the bf16 pipe with three-piece operands: six "
+                         "bf16 MFMAs of 16 clocks do the work of sixteen fp32 ones of 32; FLOP are counted as fp32 work)"}
+
+
+def measure_config1(ctx):
+    """BASELINE configs[0]: gu_maf --gu_num 1 (unimodal 2-D), B=2048, dopri5, default ODEnet; the GPU runs the W + K loop of
+    the headline on gu_num=1 batches, the CPU oracle (rank 0, N=1) the 100 iterations the config names (README.md:41)."""
+    from gan_flow_amd.gu import make_gu
+    args, world, rank, dev = ctx["args"], ctx["world"], ctx["rank"], ctx["dev"]
+    data = make_gu(1, device="cpu", seed=1 + rank, extend_dim=True)
+    n_cpu = args.config1_cpu_iters if (rank == 0 and world == 1 and "cpu" in set(args.extras.split(","))) else 0
+    xs = [data.get_sample(args.batch) for _ in range(max(args.warmup + args.steps, 5 + n_cpu))]
+    _, el, (nf, nb) = ctx["fused_run"]([x.to(dev) for x in xs[:args.warmup + args.steps]])
+    res = {"value": round(world * args.steps / el, 3), "unit": "iters/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+           "nfe_forward": nf, "nfe_backward": nb,
+           "workload": "FFJORD CNF gu_maf --gu_num 1 (unimodal 2-D), B=%d, dopri5 1e-5, default ODEnet, seed-1 init" % args.batch}
+    if n_cpu > 0:
+        import oracle
+        ncores = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(ncores)
+        torch.manual_seed(1)
+        om = oracle.build_cnf(2).train()
+        oopt = torch.optim.Adam(om.parameters(), lr=1e-3, weight_decay=1e-5)
+
+        def ostep(x):
+            oopt.zero_grad(set_to_none=True)
+            z, dl = om(x, torch.zeros(x.shape[0], 1))
+            (-(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()).backward()
+            oopt.step()
+
+        for x in xs[:5]:
+            ostep(x)
+        t0 = time.perf_counter()
+        for x in xs[5:5 + n_cpu]:
+            ostep(x)
+        cel = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(n_cpu / cel, 4), "unit": "iters/s", "cores": ncores, "kind": "port",
+                               "sample": "%d training iterations after 5 warm-up (the run BASELINE configs[0] names) of the "
+                                         "PyTorch-CPU oracle, same seed-1 init and batches, %.1f s, torch.set_num_threads(%d)"
+                                         % (n_cpu, cel, ncores)}
+        res["vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    return res
 
 
 def measure_d16(ctx):

@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-KERNEL = "dopri5_bwd_split_kernel<2, false>"
+KERNEL = "dopri5_bwd_split_kernel<2, false, true>"
 
 
 def per_launch(path, counter):
@@ -27,8 +27,8 @@ out = {"kernel": KERNEL, "launches": n, "FETCH_SIZE_KB_per_launch": round(fetch,
               "launched with CNF_FLAG_SPREAD, as the training step launches it); the six NFE-14 launches (seed-1 init, B=2048: "
               "the bench's roofline problem); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read correction of "
               "MI355X_MICROARCH.md (HBM section)",
-       "note": "per-workgroup parameter-gradient slabs (256 x 36.9 KB, half of each written): stored by the first accepted step, "
-               "read-modify-written by the later ones, read once by the slab-sum kernel. Algorithmic bytes of the launch: "
-               "4*B*(4d+3) + 4*P = 127 KB"}
+       "note": "per-workgroup parameter-gradient slabs (256 x 36.9 KB, half of each written): stored ONCE when the solve ends "
+               "(running totals in registers / LDS), read once by the slab-sum kernel. Algorithmic bytes of the launch: "
+               "4*B*(4d+3) + 4*P = 127 KB; single-write figure 127 KB + 256 x 18.4 KB = 4.8 MB"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
