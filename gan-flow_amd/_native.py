@@ -26,6 +26,15 @@ class CnfSolverOpts(ctypes.Structure):
                 ("flags", ctypes.c_int32), ("after", ctypes.c_void_p)]
 
 
+GU_MAX_MIXTURE = 16
+
+
+class CnfGuDesc(ctypes.Structure):
+    _fields_ = [("n_mixture", ctypes.c_int32), ("extend_dim", ctypes.c_int32), ("mean", ctypes.c_float * GU_MAX_MIXTURE),
+                ("sigma", ctypes.c_float * GU_MAX_MIXTURE), ("unif_intsect", ctypes.c_float * GU_MAX_MIXTURE),
+                ("unif_p", ctypes.c_float * GU_MAX_MIXTURE)]
+
+
 class CnfAdamOpts(ctypes.Structure):
     _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
                 ("weight_decay", ctypes.c_double)]
@@ -43,7 +52,7 @@ STATUS_MESSAGES = {
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
            "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
            "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation", "cnf_debug_eval_field_b16",
-           "cnf_solve_fwd_static", "cnf_static_scratch_bytes")
+           "cnf_solve_fwd_static", "cnf_static_scratch_bytes", "cnf_gu_sample")
 
 
 def library_path(act="tanh"):
@@ -82,6 +91,8 @@ def load_library(act="tanh"):
     lib.cnf_solve_fwd_static.argtypes = [ND, P, P, P, P, I64, F, F, SO, P, P, P, VP]
     lib.cnf_static_scratch_bytes.restype = SZ
     lib.cnf_static_scratch_bytes.argtypes = []
+    lib.cnf_gu_sample.restype = ctypes.c_int
+    lib.cnf_gu_sample.argtypes = [ctypes.POINTER(CnfGuDesc), ctypes.c_uint64, P, I64, P, VP]
     lib.cnf_eval_aug.restype = ctypes.c_int
     lib.cnf_eval_aug.argtypes = [ND, P, F, P, P, P, P, I64, P, P, P, P, VP, SZ, VP]
     lib.cnf_solve_bwd.restype = ctypes.c_int
@@ -396,6 +407,32 @@ def adam_step(params, grad, exp_avg, exp_avg_sq, state, lr=1e-3, betas=(0.9, 0.9
     with torch.cuda.device(params.device):
         _check(lib.cnf_adam_step(_ptr(params), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(state), n,
                                  ctypes.byref(o), ctypes.c_void_p(_stats_ptr(guard)), _stream()), lib)
+
+
+def gu_desc(mean, sigma, unif_intsect, unif_p, extend_dim):
+    n = len(mean)
+    if not 1 <= n <= GU_MAX_MIXTURE:
+        raise CnfError("the device sampler holds 1..%d mixture components (got %d)" % (GU_MAX_MIXTURE, n))
+    d = CnfGuDesc(n, 1 if extend_dim else 0)
+    for i in range(n):
+        d.mean[i], d.sigma[i], d.unif_intsect[i], d.unif_p[i] = float(mean[i]), float(sigma[i]), float(unif_intsect[i]), float(unif_p[i])
+    return d
+
+
+def gu_sample(desc, seed, state, out):
+    """cnf_gu_sample: fill `out` (rows x (2 if extend_dim else 1), fp32, on the device) with a fresh batch of the mixture;
+    `state` = 2 int32 on the device ({call number, internal}), zeroed before the first call."""
+    lib = load_library()
+    cols = 2 if desc.extend_dim else 1
+    if not (torch.is_tensor(out) and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.dim() == 2
+            and out.shape[1] == cols):
+        raise CnfError("out must be a contiguous fp32 (rows, %d) tensor on the HIP device" % cols)
+    if not (torch.is_tensor(state) and state.is_cuda and state.dtype == torch.int32 and state.numel() == 2):
+        raise CnfError("state must be 2 int32 words on the HIP device")
+    with torch.cuda.device(out.device):
+        _check(lib.cnf_gu_sample(ctypes.byref(desc), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(state), out.shape[0], _ptr(out),
+                                 _stream()), lib)
+    return out
 
 
 def debug_fill_lds(pattern=0x7FC00000, device=None):

@@ -24,6 +24,8 @@ hipError_t launch_nll_loss(const float* z, const float* dlogp, long rows, int di
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state, long n, const CnfAdamOpts& o,
                        const CnfStats* guard, hipStream_t s);
 hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s);
+// training data on the device, cnf_data.hip
+hipError_t launch_gu_sample(const CnfGuDesc& d, unsigned long long seed, int* state, long rows, float* out, hipStream_t s);
 // hidden width 256, forward path (cnf_wide.hip)
 hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
                              float* f_out, float* nd_out, hipStream_t s, float res);
@@ -514,6 +516,20 @@ int cnf_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
                     opts->beta1, opts->beta2, opts->eps, opts->weight_decay);
     hipError_t err = cnf::launch_adam(params, grad, exp_avg, exp_avg_sq, state, n, *opts, guard, (hipStream_t)stream);
     if (err != hipSuccess) return fail("cnf_adam_step: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int cnf_gu_sample(const CnfGuDesc* gu, uint64_t seed, int32_t* state, int64_t rows, float* out, void* stream) {
+    if (!gu || !state || !out) return fail("cnf_gu_sample: NULL pointer");
+    if (rows <= 0) return fail("cnf_gu_sample: rows must be positive (got %ld)", (long)rows);
+    if (gu->n_mixture < 1 || gu->n_mixture > CNF_GU_MAX_MIXTURE)
+        return fail("cnf_gu_sample: n_mixture must be 1..%d (got %d)", CNF_GU_MAX_MIXTURE, gu->n_mixture);
+    for (int c = 0; c < gu->n_mixture; ++c)
+        if (!(gu->sigma[c] > 0.f) || !(gu->unif_intsect[c] >= 0.f) || !(gu->unif_p[c] >= 0.f && gu->unif_p[c] <= 1.f) ||
+            !std::isfinite(gu->mean[c]))
+            return fail("cnf_gu_sample: component %d: need sigma > 0, unif_intsect >= 0, 0 <= unif_p <= 1, finite mean", c);
+    hipError_t err = cnf::launch_gu_sample(*gu, seed, state, rows, out, (hipStream_t)stream);
+    if (err != hipSuccess) return fail("cnf_gu_sample: launch failed: %s", hipGetErrorString(err));
     return 0;
 }
 

@@ -19,6 +19,7 @@ class GausUniffMixture:
                  extend_dim=False):
         np.random.seed(seed)
         torch.manual_seed(seed)
+        self.seed = seed
         self.device = torch.device(device)
         self.n_mixture = n_mixture
         self.mean = np.cumsum(tuple(_per_component(mean_dist, n_mixture)))
@@ -50,6 +51,11 @@ class GausUniffMixture:
             dat = torch.cat((dat, torch.rand(size=dat.size(), device=self.device)), 1)
         return dat
 
+    def device_sampler(self, device, seed=None):
+        """The same distribution drawn ON the GPU by the library's kernel (cnf_gu_sample): no host sampler, no copy per
+        iteration.  Another random stream than get_sample's (numpy's global state cannot be reproduced on a device)."""
+        return DeviceSampler(self, device, self.seed if seed is None else seed)
+
     def density(self, x):
         total = 0.0
         for c in range(self.n_mixture):
@@ -58,6 +64,27 @@ class GausUniffMixture:
             gaus = np.exp(-((x - self.mean[c]) / self.sigma[c]) ** 2 / 2) / (np.sqrt(2 * math.pi) * self.sigma[c])
             total = total + (gaus * (1 - self.unif_p[c]) + unif * self.unif_p[c]) / self.n_mixture
         return total
+
+
+class DeviceSampler:
+    """Batches of a GausUniffMixture drawn by the HIP kernel behind cnf_gu_sample (include/cnf_hip.h).
+    `fill(out)` writes a fresh batch into a (rows, 1 | 2) fp32 tensor on the device -- inside a captured graph too: the call
+    counter lives in device memory and the kernel advances it, so every replay draws new rows."""
+
+    def __init__(self, mixture, device, seed):
+        from . import _native
+        self._native = _native
+        self.device = torch.device(device)
+        self.seed = int(seed)
+        self.cols = 2 if mixture.extend_dim else 1
+        self.desc = _native.gu_desc(mixture.mean, mixture.sigma, mixture.unif_intsect, mixture.unif_p, mixture.extend_dim)
+        self.state = torch.zeros(2, dtype=torch.int32, device=self.device)
+
+    def fill(self, out):
+        return self._native.gu_sample(self.desc, self.seed, self.state, out)
+
+    def get_sample(self, size):
+        return self.fill(torch.empty(size, self.cols, dtype=torch.float32, device=self.device))
 
 
 def make_gu(gu_num, device="cpu", seed=1, extend_dim=True):

@@ -64,7 +64,8 @@ def count_nfe(model):
 
 def evaluate_w_distance(model, data, eval_size=100000, chunk=10000, device=None):
     """The reference's sampling protocol (model_plot.py:93-101): eval_size prior draws pushed through sample_fn in
-    10 000-row chunks, 1-D Wasserstein distance of the first coordinate against fresh data."""
+    10 000-row chunks, 1-D Wasserstein distance of the first coordinate against fresh data.  `data`: anything with
+    get_sample(n) -- the host mixture, or its DeviceSampler (then nothing leaves the GPU but the final number)."""
     device = device or next(model.parameters()).device
     dim = model.chain[0].odefunc.odefunc.diffeq.dims[0]
     was_training = model.training
@@ -147,7 +148,15 @@ class FusedTrainStep:
     device until .check()."""
 
     def __init__(self, model, example_batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, graph=True,
-                 warmup_batches=(), spread=True, fuse_tail=True):
+                 warmup_batches=(), spread=True, fuse_tail=True, sampler=None, warmup=0):
+        # sampler: a gu.DeviceSampler (or anything with .fill(tensor)): every iteration starts by drawing its batch on the
+        # device straight into the static input (one more kernel in the captured graph, no host sampler, no copy) and
+        # step() takes no argument; `warmup` such iterations run before the capture (warmup_batches is for fed batches)
+        self.sampler = sampler
+        if sampler is not None and len(warmup_batches):
+            raise ValueError("with a device sampler the warm-up iterations draw their own batches: pass warmup=N")
+        if sampler is not None:
+            warmup_batches = [None] * int(warmup)
         # fuse_tail: use cnf_solve_bwd_train (same arithmetic, fewer kernels) where it is built
         self.fuse_tail = bool(fuse_tail)
         # spread: flag the adjoint solves CNF_FLAG_SPREAD (include/cnf_hip.h): two workgroups per 16-row tile when the
@@ -180,7 +189,8 @@ class FusedTrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for xb in warmup_batches:
-                    self.static_x.copy_(xb)
+                    if xb is not None:
+                        self.static_x.copy_(xb)
                     self._iteration()
                 if not len(warmup_batches):          # capture needs the library loaded and the workspace allocated
                     self._dry_run()
@@ -192,7 +202,8 @@ class FusedTrainStep:
                 self.static_loss = self._iteration()
         else:
             for xb in warmup_batches:
-                self.static_x.copy_(xb)
+                if xb is not None:
+                    self.static_x.copy_(xb)
                 self._iteration()
 
     def _dry_run(self):
@@ -208,6 +219,8 @@ class FusedTrainStep:
         # every solve names the stats block of the solve before it (CnfSolverOpts.after): a failure anywhere makes all
         # later solves of the iteration exit at once with that status, and the Adam updates skip themselves -- the
         # parameters are never updated from the garbage a failed solve leaves behind
+        if self.sampler is not None:
+            self.sampler.fill(self.static_x)
         z, lp, tape, prev = self.static_x, None, [], None
         for i, blk in enumerate(self.blocks):
             net, t0, t1, opts, e = blk.solve_plan(z, reset_counter=False)
@@ -239,8 +252,11 @@ class FusedTrainStep:
                 nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], guard=prev, **self.hyper)
         return loss
 
-    def __call__(self, x):
-        self.static_x.copy_(x, non_blocking=True)
+    def __call__(self, x=None):
+        if (x is None) != (self.sampler is not None):
+            raise ValueError("pass a batch, or build the step with sampler= and call it without one")
+        if x is not None:
+            self.static_x.copy_(x, non_blocking=True)
         if self.graph is not None:
             self.graph.replay()
             return self.static_loss
@@ -410,6 +426,9 @@ def parse_args(argv=None):
     p.add_argument("--eval_logp_size", type=int, default=20000, help="fresh data points for the E[log p] estimate at log points")
     p.add_argument("--fused", type=int, default=1, help="1: FusedTrainStep (library kernels only, one hipGraph replay per "
                    "iteration); 0: autograd + torch.optim.Adam loop")
+    p.add_argument("--device_sampler", type=int, default=1, help="1: draw the training and evaluation data on the GPU "
+                   "(cnf_gu_sample, same distribution as gu.py's host sampler, another random stream); 0: the reference's "
+                   "numpy sampler on the host + a copy per iteration")
     return p.parse_args(argv)
 
 
@@ -440,9 +459,11 @@ def main(argv=None):
     logger.info("parameters: %d" % count_parameters(model))
     model.train()
     fused = optimizer = None
+    on_device = data.device_sampler(device) if args.device_sampler else None
+    train_sampler = on_device if (args.fused and on_device is not None) else None
     if args.fused:
         x = data.get_sample(args.batch_size).to(device)
-        fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay)
+        fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay, sampler=train_sampler)
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=True)
         for block in model.chain:          # one training per GPU: the adjoint may use both halves of the chip
@@ -454,11 +475,13 @@ def main(argv=None):
         model.load_state_dict(ck["model"])
         start_itr = int(ck["itr"])
         if fused is not None:
-            fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay)   # parameters were re-assigned: re-alias
+            fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay, sampler=train_sampler)   # parameters were re-assigned: re-alias
             fused.load_state_dict(ck["optimizer"])
         else:
             optimizer.load_state_dict(ck["optimizer"])
         data = make_gu(args.gu_num, device="cpu", seed=args.seed + start_itr, extend_dim=True)   # a fresh sample stream
+        if on_device is not None:
+            on_device.seed = args.seed + start_itr
         logger.info("resumed from %s at iteration %d" % (args.resume, start_itr))
 
     def checkpoint(itr):
@@ -474,7 +497,7 @@ def main(argv=None):
         for b in model.chain:
             b.tile_rows = 16          # evaluation: every 16-row tile controls its own step
         with torch.no_grad():
-            lp = model_log_prob(model, data.get_sample(args.eval_logp_size).to(device)).mean().item()
+            lp = model_log_prob(model, (on_device or data).get_sample(args.eval_logp_size).to(device)).mean().item()
         for b in model.chain:
             b.tile_rows = 0
         model.train(was_training)
@@ -483,7 +506,7 @@ def main(argv=None):
     t_start = t_last = time.time()
     itr_last = start_itr
     for itr in range(start_itr + 1, args.niters + 1):
-        x = data.get_sample(args.batch_size).to(device)
+        x = None if train_sampler is not None else (on_device or data).get_sample(args.batch_size).to(device)
         log_now = itr % args.log_interval == 0 or itr == start_itr + 1 or itr == args.niters
         if fused is not None:
             loss = fused(x)
@@ -500,7 +523,7 @@ def main(argv=None):
             torch.cuda.synchronize()
             now = time.time()
             per_iter = (now - t_last) / max(1, itr - itr_last)
-            wd = evaluate_w_distance(model, data, args.eval_size, device=device)
+            wd = evaluate_w_distance(model, on_device or data, args.eval_size, device=device)
             lp = mean_log_likelihood()
             logger.info("iter %06d | loss %.6f | NFE fwd %d bwd %d | %.3f ms/iter = %.1f iters/s | W-distance %.4f | E[log p] %.4f | wall %.0f s"
                         % (itr, loss.item(), nfe_f, nfe_b, 1e3 * per_iter, 1.0 / per_iter, wd, lp, now - t_start))

@@ -215,6 +215,23 @@ int cnf_solve_bwd_train(const CnfNetDesc *net, float *params, const float *z1, c
                         int32_t *adam_state, const CnfAdamOpts *adam, void *workspace, size_t workspace_bytes,
                         CnfStats *stats, void *stream);
 
+/* The study's training data drawn on the device: GausUniffMixture.get_sample (/root/reference/gu.py:35-68), which the
+ * reference draws with numpy on the host and copies to the GPU every iteration.  Same distribution --
+ * rows i.i.d.: component uniform over n_mixture, then with probability unif_p[c] uniform on mean[c] +- unif_intsect[c] *
+ * sigma[c], else N(mean[c], sigma[c]^2); with extend_dim a second column U(0, 1) (gu.py:63-66) -- from another random
+ * stream (Philox4x32-10 keyed by `seed`, counter = (row, call number)): numpy's global-state stream cannot be matched on a
+ * device, the host sampler stays the bit-exact restatement.
+ *   out: rows x (extend_dim ? 2 : 1) floats;  state: 2 int32 in device memory, zeroed by the caller before the first
+ *   call: {call number, internal}; the kernel advances the call number itself, so a captured graph draws a fresh batch
+ *   at every replay.  mean[] holds the component means themselves (the reference's cumulative sums of mean_dist).   */
+enum { CNF_GU_MAX_MIXTURE = 16 };
+typedef struct CnfGuDesc {
+    int32_t n_mixture;   /* 1 .. CNF_GU_MAX_MIXTURE */
+    int32_t extend_dim;  /* 0 | 1 */
+    float mean[CNF_GU_MAX_MIXTURE], sigma[CNF_GU_MAX_MIXTURE], unif_intsect[CNF_GU_MAX_MIXTURE], unif_p[CNF_GU_MAX_MIXTURE];
+} CnfGuDesc;
+int cnf_gu_sample(const CnfGuDesc *gu, uint64_t seed, int32_t *state, int64_t rows, float *out, void *stream);
+
 /* Diagnostics (no counterpart in the reference): fill the LDS of every compute unit with `pattern`.  LDS keeps the
  * previous kernel's content, so the tests poison it (NaN bit patterns) before a solve to prove that no result
  * depends on it.  scratch_word: one uint32 of device memory (never written in practice).                    */

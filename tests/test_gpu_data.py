@@ -1,0 +1,149 @@
+"""GPU: the study's data and metric on the device.
+
+  * cnf_gu_sample (the mixture of /root/reference/gu.py:35-68 drawn by a HIP kernel) against the analytic CDF of that
+    mixture (Kolmogorov-Smirnov), against the bit-exact host restatement (two-sample KS), and against the moments of the
+    vectors generated from the reference itself (tests/golden/gu_samples.npz).  The random stream differs by construction
+    (numpy's global state cannot be matched on a device): the bar is equality IN DISTRIBUTION;
+  * util.w_distance on device tensors against scipy.stats.wasserstein_distance (what /root/reference/util.py:16-20 calls);
+  * FusedTrainStep fed by the device sampler inside its captured graph: a fresh batch per replay, training proceeds;
+  * BASELINE configs[0] (gu_num = 1 data): the fused training step against the CPU oracle, iteration by iteration.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import stats
+
+import oracle
+from _helpers import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mixture_cdf(gu, x):
+    total = np.zeros_like(x, dtype=np.float64)
+    for c in range(gu.n_mixture):
+        lo, hi = gu._bounds(c)
+        unif = np.clip((x - lo) / (hi - lo), 0.0, 1.0)
+        gaus = stats.norm.cdf(x, loc=gu.mean[c], scale=gu.sigma[c])
+        total += (gaus * (1 - gu.unif_p[c]) + unif * gu.unif_p[c]) / gu.n_mixture
+    return total
+
+
+@pytest.mark.parametrize("gu_num", [1, 8])
+def test_device_sampler_draws_the_reference_distribution(gu_num):
+    from gan_flow_amd.gu import make_gu
+    gu = make_gu(gu_num, seed=3, extend_dim=True)
+    smp = gu.device_sampler(DEV, seed=11)
+    n = 400000
+    a = smp.get_sample(n)
+    b = smp.get_sample(n)
+    torch.cuda.synchronize()
+    assert a.shape == (n, 2) and not torch.equal(a, b)                      # every call draws a fresh batch
+    again = gu.device_sampler(DEV, seed=11).get_sample(n)
+    assert torch.equal(again, a)                                            # same seed, same call number: same batch
+    assert smp.state.tolist() == [2, 0]
+    x = a[:, 0].double().cpu().numpy()
+    u = a[:, 1].double().cpu().numpy()
+    # one-sample KS against the analytic mixture CDF and against U(0, 1) for the nuisance column
+    ks = stats.kstest(x, lambda v: _mixture_cdf(gu, v))
+    ku = stats.kstest(u, "uniform")
+    print("gu_num %d: KS vs analytic CDF D=%.2e p=%.3f | nuisance column D=%.2e p=%.3f" % (gu_num, ks.statistic, ks.pvalue, ku.statistic, ku.pvalue))
+    assert ks.pvalue > 1e-3 and ku.pvalue > 1e-3
+    assert abs(np.corrcoef(x, u)[0, 1]) < 0.01 and u.min() >= 0.0 and u.max() < 1.0
+    # two-sample KS against the bit-exact host restatement of the reference's sampler
+    host = gu.get_sample(200000)[:, 0].double().numpy()
+    k2 = stats.ks_2samp(x, host)
+    assert k2.pvalue > 1e-3, k2
+    # moments of the vectors generated from the reference itself (make_gu_vectors.py)
+    gold = np.load(os.path.join(GOLDEN, "gu_samples.npz"))
+    ref = np.concatenate([gold[("uni" if gu_num == 1 else "multi") + "_ext0_" + k].reshape(-1) for k in "ab"]).astype(np.float64)
+    se = ref.std() / np.sqrt(ref.size)
+    assert abs(x.mean() - ref.mean()) < 6 * se and abs(x.std() - ref.std()) < 0.1 * ref.std()
+    assert stats.ks_2samp(x[:20000], ref).pvalue > 1e-3
+    # analytic moments
+    m_true = float(np.mean(gu.mean))
+    assert abs(x.mean() - m_true) < 5 * x.std() / np.sqrt(n)
+
+
+def test_device_sampler_rejects_bad_arguments():
+    from gan_flow_amd import _native as nat
+    from gan_flow_amd.gu import GausUniffMixture, make_gu
+    smp = make_gu(8, extend_dim=False).device_sampler(DEV)
+    assert smp.get_sample(100).shape == (100, 1)
+    with pytest.raises(nat.CnfError):
+        smp.fill(torch.empty(100, 2, device=DEV))
+    with pytest.raises(nat.CnfError):
+        smp.fill(torch.empty(100, 1))
+    with pytest.raises(nat.CnfError):
+        GausUniffMixture(17, 1.0, 1.0, 1.0).device_sampler(DEV)
+
+
+def test_w_distance_on_device_matches_scipy():
+    from gan_flow_amd.util import w_distance
+    g = torch.Generator().manual_seed(2)
+    for na, nb in ((100000, 100000), (5000, 3000)):
+        a = torch.randn(na, generator=g) * 3 + 1
+        b = torch.rand(nb, generator=g) * 8 - 2
+        ref = float(np.round(stats.wasserstein_distance(a.numpy(), b.numpy()), 4))
+        got = w_distance(a.to(DEV), b.to(DEV))
+        assert abs(got - ref) <= 1.01e-4, (got, ref)
+
+
+def test_fused_training_fed_by_the_device_sampler():
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    torch.manual_seed(1)
+    model = gu_ffjord.build_model(2).to(DEV).train()
+    smp = make_gu(8, seed=1).device_sampler(DEV)
+    step = gu_ffjord.FusedTrainStep(model, torch.zeros(2048, 2, device=DEV), lr=1e-3, weight_decay=1e-5, graph=True, sampler=smp, warmup=2)
+    seen, losses = [], []
+    for _ in range(40):
+        losses.append(step().item())
+        seen.append(step.static_x[:4, 0].clone())
+    nfe = step.check()
+    assert step.step_count == 42 and nfe[0] >= 14
+    assert all(not torch.equal(seen[i], seen[i + 1]) for i in range(len(seen) - 1))       # a fresh batch at every replay
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
+    with pytest.raises(ValueError):
+        step(torch.zeros(2048, 2, device=DEV))
+    # the evaluation protocol with nothing on the host: samples, real data and the sort all on the device
+    wd = gu_ffjord.evaluate_w_distance(model, smp, eval_size=20000, device=torch.device(DEV))
+    assert np.isfinite(wd) and wd > 0
+
+
+def test_config1_unimodal_training_matches_the_oracle():
+    """BASELINE configs[0]: `gu_maf --gu_num 1`, B = 2048, dopri5, default ODEnet.  Five training iterations on the same
+    gu_num = 1 batches from the same seed-1 init: losses, evaluation counts and the trained weights against the CPU oracle."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    data = make_gu(1, seed=1, extend_dim=True)
+    xs = [data.get_sample(2048) for _ in range(5)]
+    assert abs(float(xs[0][:, 0].mean()) - 5.0) < 0.05 and float(xs[0][:, 1].min()) >= 0.0
+    torch.manual_seed(1)
+    mo = oracle.build_cnf(2).train()
+    mp = gu_ffjord.build_model(2)
+    mp.load_state_dict(mo.state_dict())
+    mp = mp.to(DEV).train()
+    oopt = torch.optim.Adam(mo.parameters(), lr=1e-3, weight_decay=1e-5)
+    step = gu_ffjord.FusedTrainStep(mp, xs[0].to(DEV), lr=1e-3, weight_decay=1e-5, graph=False)
+    for i, x in enumerate(xs):
+        oopt.zero_grad(set_to_none=True)
+        z, dl = mo(x, torch.zeros(2048, 1))
+        lo = -(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()
+        lo.backward()
+        oopt.step()
+        lp = step(x.to(DEV)).item()
+        nf, nb = step.check()
+        so = mo.chain[0].stats
+        print("config 1 iteration %d: loss hip %.6f oracle %.6f | NFE hip %d/%d oracle %d/%d"
+              % (i, lp, lo.item(), nf, nb, 2 + 6 * (so["forward"]["n_accepted"] + so["forward"]["n_rejected"]),
+                 2 + 6 * (so["backward"]["n_accepted"] + so["backward"]["n_rejected"])))
+        assert abs(lp - lo.item()) <= 2e-5 * abs(lo.item())
+        assert nf == 2 + 6 * (so["forward"]["n_accepted"] + so["forward"]["n_rejected"])
+        assert nb == 2 + 6 * (so["backward"]["n_accepted"] + so["backward"]["n_rejected"])
+    po = torch.cat([p.detach().reshape(-1) for p in mo.chain[0].odefunc.odefunc.diffeq.parameters()])
+    pp = torch.cat([p.detach().reshape(-1) for p in mp.chain[0].odefunc.odefunc.diffeq.parameters()]).cpu()
+    assert (po - pp).abs().max().item() < 5e-5            # five Adam steps of 1e-3 each moved the weights by ~5e-3

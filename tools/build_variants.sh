@@ -11,7 +11,7 @@ while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   /opt/rocm/bin/hipcc $FLAGS $defs -c $SRC.hip -o ../variants/${SRC}_$name.o
   objs=""
-  for o in cnf_fwd cnf_bwd cnf_split cnf_split16 cnf_wide cnf_wide_bwd cnf_train cnf_api; do
+  for o in cnf_fwd cnf_bwd cnf_split cnf_split16 cnf_wide cnf_wide_bwd cnf_train cnf_data cnf_api; do
     if [ $o = $SRC ]; then objs="$objs ../variants/${SRC}_$name.o"; else objs="$objs $o.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libcnf_hip_$name.so $objs
