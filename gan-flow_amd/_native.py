@@ -215,6 +215,7 @@ class Stats:
 
 FLAG_CLEAN = 1   # CNF_FLAG_CLEAN, include/cnf_hip.h
 FLAG_SPREAD = 2  # CNF_FLAG_SPREAD
+FLAG_ADJ_CONTROL_ALL = 4  # CNF_FLAG_ADJ_CONTROL_ALL: a_z and a_logp under the adjoint solve's step control as well
 
 
 def make_opts(solver="dopri5", rtol=1e-5, atol=1e-5, step_size=None, tile_rows=0, max_steps=0, flags=0, after=None):

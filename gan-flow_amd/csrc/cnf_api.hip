@@ -220,7 +220,7 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
     a.step_size = 0.f;
     a.after = opts->after;
     if (opts->after == stats) return fail("%s: opts->after must be another block than this solve's stats", who);
-    if (opts->flags & ~(CNF_FLAG_CLEAN | CNF_FLAG_SPREAD)) return fail("%s: unknown bits in opts->flags (0x%x)", who, (unsigned)opts->flags);
+    if (opts->flags & ~(CNF_FLAG_CLEAN | CNF_FLAG_SPREAD | CNF_FLAG_ADJ_CONTROL_ALL)) return fail("%s: unknown bits in opts->flags (0x%x)", who, (unsigned)opts->flags);
     global = true;
     if (opts->solver == CNF_SOLVER_DOPRI5) {
         if (!(opts->rtol > 0.f) || !(opts->atol > 0.f)) return fail("%s: dopri5 needs rtol > 0 and atol > 0", who);
@@ -434,6 +434,7 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
     a.grad_logp0 = grad_logp0;
     a.grad_params = grad_params;
     a.spread = (opts->flags & CNF_FLAG_SPREAD) && can_spread(net, rows, device_cus()) ? 1 : 0;
+    a.adj_all = (opts->flags & CNF_FLAG_ADJ_CONTROL_ALL) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (is_wide(net)) {
         if (((uintptr_t)params & 15) != 0) return fail("%s: params must be 16-byte aligned for hidden width 256", who);

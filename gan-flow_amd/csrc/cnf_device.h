@@ -159,6 +159,7 @@ struct alignas(16) RedLds {
     double tot[4];
     int status;
     int last;   // grid_cleanup: this workgroup took the last ticket
+    float keep[2];   // CNF_FLAG_ADJ_CONTROL_ALL: d1 of a_z between the two evaluations of the initial step (written by thread 0)
 };
 
 // everything of the net except the two 64x64 matrices: first / last layer weights and the per-layer vectors
@@ -650,6 +651,63 @@ __device__ __forceinline__ double next_step_size(double dt, float worst) {
 
 // python's max(a, b) over a 2-tuple: keeps `a` unless b > a (so a NaN in `a` sticks, one in `b` is ignored)
 __device__ __forceinline__ float pymax(float a, float b) { return b > a ? b : a; }
+
+// ---- CNF_FLAG_ADJ_CONTROL_ALL: which tensors of the adjoint state the step controller looks at ------------------------
+// The reference hands odeint_adjoint tolerance LISTS of length 2, and torchdiffeq 0.0.1 zips tolerances with the state
+// tuple: in the backward solve only (z, logp) drive the error ratios (recalled, unverifiable
+// offline) -- the default here.  With the flag, the per-row tensors of the adjoint state, a_z and a_logp, are controlled
+// like z and logp (what scalar tolerances would do to them): each contributes its own mean-square error ratio and its own
+// terms to the initial-step heuristic, in the state tuple's order (z, logp, a_z, a_logp).  a_logp never changes, so its
+// error ratio is 0 and its d1 is 0 -- which makes d0 / d1 = +inf (or 0 / 0 = NaN when the cotangent is zero) in the
+// heuristic exactly as it does in the original's arithmetic: h0 = inf, the second evaluation sees a non-finite state, its
+// d2 terms come out as 0 or NaN, python's max() skips NaNs that are not its first argument, and the first step is
+// (0.01 / max(d1))^(1/5).  The kernels reproduce that outcome without evaluating the field at infinity (the evaluation is
+// still run, at the initial state, and counted).  a_t and a_theta (batch-level quadratures, not per-row state) stay
+// outside the controller in both modes: see DESIGN.md section 5.
+template <int D, int C>
+__device__ __forceinline__ void adj_all_f0_sums(const float (&y0)[C], const float (&k)[C], float al, float rtol, float atol,
+                                                bool counted, double (&S)[4]) {
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        const int c = D + 1 + m;
+        const float s = atol + fabsf(y0[c]) * rtol;
+        const float u = y0[c] / s, v = k[c] / s;
+        if (counted) {
+            S[0] += (double)u * u;
+            S[1] += (double)v * v;
+        }
+    }
+    const float ua = al / (atol + fabsf(al) * rtol);
+    if (counted) S[2] += (double)ua * ua;
+}
+// h0 of the heuristic (Appendix B.2) from the d0 / d1 of (z, logp[, a_z, a_logp]); d1 of a_logp is identically zero
+__device__ __forceinline__ float initial_h0(float d0z, float d0l, float d1z, float d1l, bool all, float d0a, float d1a, float d0al) {
+    float m0 = pymax(d0z, d0l), m1 = pymax(d1z, d1l), mr = pymax(d0z / d1z, d0l / d1l);
+    if (all) {
+        const float zero = 0.f;
+        m0 = pymax(pymax(m0, d0a), d0al);
+        m1 = pymax(pymax(m1, d1a), zero);
+        mr = pymax(pymax(mr, d0a / d1a), d0al / zero);
+    }
+    return (m0 < 1e-5f || m1 < 1e-5f) ? 1e-6f : 0.01f * mr;
+}
+// the first step size from h0 and the d1 / d2 terms, in the tuple order python's max() walks them
+__device__ __forceinline__ float initial_dt(float h0, float d1z, float d1l, float d2z, float d2l, bool all, float d1a, float d2a) {
+    const bool inf0 = all && !(h0 < INFINITY);   // see above: the d2 terms are 0 or NaN then, never the maximum
+    if (inf0) d2z = d2l = d2a = 0.f;
+    float m1 = pymax(d1z, d1l), m2 = pymax(d2z, d2l), mm;
+    if (all) {
+        m1 = pymax(pymax(m1, d1a), 0.f);
+        m2 = pymax(pymax(m2, d2a), 0.f);
+        mm = pymax(pymax(pymax(m1, d2z), d2l), d2a);
+    } else {
+        mm = pymax(pymax(m1, d2z), d2l);
+    }
+    float h1;
+    if (!inf0 && m1 <= 1e-15f && m2 <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);
+    else h1 = powf(0.01f / mm, 0.2f);
+    return fminf(100.f * h0, h1);
+}
 
 // ---- grid-wide reduction of up to 4 doubles -----------------------------------------------------
 // Every workgroup publishes its partial as four 8-byte {epoch, value} granules (one sc1 store each: the

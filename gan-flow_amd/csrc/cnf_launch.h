@@ -33,6 +33,7 @@ struct SolveArgs {
                           // loss goes here
     int residual;         // CNF_DIV_RESIDUAL: the dynamics are f(z) - z (ODEfunc(residual=True))
     int keep_slabs;       // adjoint: leave the per-workgroup gradient slabs for launch_adam_slabs (no reduction kernel)
+    int adj_all;          // adjoint, CNF_FLAG_ADJ_CONTROL_ALL: a_z and a_logp under step control as well (cnf_device.h)
     const CnfStats* after;  // CnfSolverOpts.after (nullable): exit at once with that block's status when it is non-zero
 };
 

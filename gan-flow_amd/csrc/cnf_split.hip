@@ -1115,14 +1115,22 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
             d1z = (float)sqrt(S[2] / nz);
             d1l = (float)sqrt(S[3] / nl);
-            if (pymax(d0z, d0l) < 1e-5f || pymax(d1z, d1l) < 1e-5f) {
-                h0 = 1e-6f;
-            } else {
-                h0 = 0.01f * pymax(d0z / d1z, d0l / d1l);
+            float d0a = 0.f, d1a = 0.f, d0al = 0.f;
+            if (a.adj_all) {   // CNF_FLAG_ADJ_CONTROL_ALL (cnf_device.h): a_z and a_logp take part in the heuristic
+                double S2[4] = {0, 0, 0, 0};
+                adj_all_f0_sums<D, C>(y0, k, al, rtol, atol, counted, S2);
+                if (!wg_allreduce4(gs, red, S2, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                d0a = (float)sqrt(S2[0] / nz);
+                d1a = (float)sqrt(S2[1] / nz);
+                d0al = (float)sqrt(S2[2] / nl);
+                if (tid == 0) red.keep[0] = d1a;   // read after the next reduction's barriers
             }
+            h0 = initial_h0(d0z, d0l, d1z, d1l, a.adj_all != 0, d0a, d1a, d0al);
+            if (h0 < INFINITY) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) yi[c] = y0[c] + h0 * k[c];
-            ti = t0f + h0;
+                for (int c = 0; c < C; ++c) yi[c] = y0[c] + h0 * k[c];
+                ti = t0f + h0;
+            }   // else (adj_all): the second evaluation runs at the initial state; initial_dt() ignores what it returns
             phase = PH_F1;
             continue;
         }
@@ -1134,16 +1142,19 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                 if (counted) S[c < D ? 0 : 1] += (double)u * u;
             }
             if (nll && counted) S[2] = (double)nll_row;
+            if (a.adj_all && counted) {
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    const int c = D + 1 + m;
+                    const float u = (k[c] - ws.kst[0][c][j]) / (atol + fabsf(y0[c]) * rtol);
+                    S[3] += (double)u * u;
+                }
+            }
             if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * inv_rows);
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
-            float h1;
-            if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
-                h1 = fmaxf(1e-6f, h0 * 1e-3f);
-            } else {
-                h1 = powf(0.01f / pymax(pymax(pymax(d1z, d1l), d2z), d2l), 0.2f);
-            }
-            dt = (double)fminf(100.f * h0, h1);
+            const float d2a = (float)sqrt(S[3] / nz) / h0;
+            dt = (double)initial_dt(h0, d1z, d1l, d2z, d2l, a.adj_all != 0, a.adj_all ? red.keep[0] : 0.f, d2a);
             restart = true;
         } else {
 #pragma unroll
@@ -1166,12 +1177,24 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                         if (!isfinite(y0[c])) S[2] += 1.0;
                     }
                 }
+                if (a.adj_all) {   // a_z under error control as well
+#pragma unroll
+                    for (int m = 0; m < D; ++m) {
+                        const int c = D + 1 + m;
+                        float err = 0.f;
+#pragma unroll
+                        for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                        const float u = err / (atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c])));
+                        if (counted) S[3] += (double)u * u;
+                    }
+                }
                 pr.mark(21);
                 if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 pr.mark(22);
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
                 const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
-                const bool accept = (rz <= 1.f) && (rl <= 1.f);
+                const float ra = (float)(S[3] / nz);   // 0 unless CNF_FLAG_ADJ_CONTROL_ALL (a_logp's ratio is always 0)
+                const bool accept = (rz <= 1.f) && (rl <= 1.f) && (ra <= 1.f);
                 if (accept) {
                     ++nacc;
                     if constexpr (RUNTOT) commit_total<D>(sb, total, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], tid, part);
@@ -1193,7 +1216,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                     ++nrej;
                 }
                 pr.mark(23);
-                dt = next_step_size(dt, pymax(rz, rl));
+                dt = next_step_size(dt, pymax(pymax(rz, rl), ra));
                 restart = true;
                 pr.mark(24);
             }

@@ -65,6 +65,10 @@ class CNF(nn.Module):
         self.sync_stats = True      # read the solver status back after every solve (one host sync, as the reference has)
         self.spread_adjoint = False  # backward(): CNF_FLAG_SPREAD, two workgroups per 16-row tile (include/cnf_hip.h); same
                                      # gradients, faster for batches <= 2048 rows; not for solves sharing a GPU with others
+        # which tensors of the adjoint state drive backward()'s step control: "state_only" =
+        # (z, logp), what the reference's length-2 tolerance lists do in torchdiffeq 0.0.1 as recalled; "all" adds
+        # (a_z, a_logp) (CNF_FLAG_ADJ_CONTROL_ALL, include/cnf_hip.h).  Neither is pinned by a reference artefact.
+        self.adjoint_error_control = "state_only"
         self.last_stats = {}
 
     # ------------------------------------------------------------------------------------------------
@@ -107,8 +111,12 @@ class CNF(nn.Module):
             solver, atol, rtol, options = self.solver, self.atol, self.rtol, self.solver_options
         else:
             solver, atol, rtol, options = self.test_solver, self.test_atol, self.test_rtol, {}
+        if self.adjoint_error_control not in ("state_only", "all"):
+            raise ValueError("adjoint_error_control must be 'state_only' or 'all' (got %r)" % (self.adjoint_error_control,))
+        flags = (_native.FLAG_SPREAD if self.spread_adjoint else 0) | \
+                (_native.FLAG_ADJ_CONTROL_ALL if self.adjoint_error_control == "all" else 0)
         opts = _native.make_opts(solver, rtol, atol, options.get("step_size"), self.tile_rows, options.get("max_num_steps", 0),
-                                 flags=_native.FLAG_SPREAD if self.spread_adjoint else 0)
+                                 flags=flags)
         return inner.net_desc(), t0, t1, opts, inner.probe(z)
 
     def forward(self, z, logpz=None, integration_times=None, reverse=False):

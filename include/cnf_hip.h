@@ -81,7 +81,7 @@ typedef struct CnfSolverOpts {
  * it timed out).  The call then enqueues no memset at all: tight loops and captured graphs save four fill nodes
  * per training iteration.  stats->status becomes sticky (it is only ever raised).  Ignored (memsets kept) where it
  * does not apply: rk4, tile-local control, more than 4096 rows.                                            */
-enum { CNF_FLAG_CLEAN = 1, CNF_FLAG_SPREAD = 2 };
+enum { CNF_FLAG_CLEAN = 1, CNF_FLAG_SPREAD = 2, CNF_FLAG_ADJ_CONTROL_ALL = 4 };
 
 /* CNF_FLAG_SPREAD (cnf_solve_bwd, at most half as many 16-row tiles as the device has
  * compute units -- 2048 rows on an MI355X; ignored otherwise): the adjoint runs TWO workgroups per tile.  Both
@@ -89,6 +89,17 @@ enum { CNF_FLAG_CLEAN = 1, CNF_FLAG_SPREAD = 2 };
  * evaluation.  Results are those of an unflagged call (same sums, added in the same order).  The launch then occupies
  * every compute unit: do not flag solves that are meant to overlap with other batch-global solves on the same device
  * (two trainings on two streams), whose workgroups must all be resident at once.                              */
+
+/* CNF_FLAG_ADJ_CONTROL_ALL (cnf_solve_bwd, cnf_solve_bwd_train; ignored by the forward solves): which tensors of the
+ * adjoint state drive the backward solve's step control.  Unflagged = `state_only`: (z, logp) alone, which is what the
+ * reference's length-2 tolerance lists do in torchdiffeq 0.0.1 as recalled (the solver zips tolerances with the state
+ * tuple; SURVEY.md Appendix D.3 -- unverifiable offline, hence this switch).  Flagged: the per-row adjoint tensors a_z and
+ * a_logp are controlled like z and logp -- each adds its own mean-square error ratio to the accept test and its own
+ * terms to the initial-step heuristic, in the order of the state tuple.  Because a_logp is constant its d1 is 0 and the
+ * heuristic's d0 / d1 is infinite, as it is in the original's arithmetic: the first step is then (0.01 / max d1)^(1/5)
+ * (cnf_device.h spells the NaN / inf bookkeeping out).  The two batch-level quadratures of the adjoint state, a_t and
+ * a_theta, stay outside the controller in both modes.  Neither mode is pinned by a reference
+ * artefact; backward NFE is the only thing that differs.                                                       */
 
 enum {
     CNF_OK = 0,
@@ -167,7 +178,8 @@ int cnf_eval_aug(const CnfNetDesc *net, const float *params, float t, const floa
 /* Backward solve: OdeintAdjointMethod.backward for the single interval [t0, t1] (a10).
  *   inputs : z1, logp1 = state at t1 saved by the forward; grad_z1, grad_logp1 = dL/d(state at t1)
  *   outputs: grad_x, grad_logp0 = dL/d(state at t0); grad_params (overwritten).
- *   Error control covers (z, logp) only, as the reference's length-2 tolerance lists imply.       */
+ *   Error control covers (z, logp) only, as the reference's length-2 tolerance lists imply; CNF_FLAG_ADJ_CONTROL_ALL
+ *   adds (a_z, a_logp).                                                                            */
 int cnf_solve_bwd(const CnfNetDesc *net, const float *params, const float *z1, const float *logp1,
                   const float *e, const float *grad_z1, const float *grad_logp1, int64_t rows,
                   float t0, float t1, const CnfSolverOpts *opts, float *grad_x, float *grad_logp0,

@@ -203,6 +203,7 @@ class CNF(nn.Module):
         self.test_solver, self.test_atol, self.test_rtol = solver, atol, rtol
         self.solver_options = {}
         self.stats = {}
+        self.adjoint_error_control = "state_only"   # | 'rows' | 'all' (odeint_adjoint)
 
     def forward(self, z, logpz=None, integration_times=None, reverse=False):
         _logpz = torch.zeros(z.shape[0], 1).to(z) if logpz is None else logpz
@@ -220,7 +221,8 @@ class CNF(nn.Module):
                 self.odefunc, (z, _logpz) + reg, integration_times.to(z),
                 atol=[self.atol, self.atol] + [1e20] * len(reg) if dop else self.atol,
                 rtol=[self.rtol, self.rtol] + [1e20] * len(reg) if dop else self.rtol,
-                method=self.solver, options=self.solver_options, stats=self.stats)
+                method=self.solver, options=self.solver_options, stats=self.stats,
+                adjoint_control=self.adjoint_error_control)
         else:
             state_t = odeint_adjoint(
                 self.odefunc, (z, _logpz), integration_times.to(z),

@@ -310,8 +310,9 @@ def _flat(tensors, like):
 
 class _Adjoint(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, func, n_state, t, rtol, atol, method, options, stats, flat_params, *y0):
+    def forward(ctx, func, n_state, t, rtol, atol, method, options, stats, control, flat_params, *y0):
         ctx.func, ctx.rtol, ctx.atol, ctx.method, ctx.options, ctx.stats = func, rtol, atol, method, options, stats
+        ctx.control = control
         with torch.no_grad():
             ans = odeint(func, tuple(y0), t, rtol=rtol, atol=atol, method=method,
                          options=dict(options or {}, stats=stats.setdefault("forward", {})))
@@ -350,21 +351,37 @@ class _Adjoint(torch.autograd.Function):
                 adj_t = adj_t - dL_dt
                 time_grads.append(dL_dt)
                 aug0 = y_i + adj_y + (adj_t, adj_p)
-                sol = odeint(augmented, aug0, torch.stack([t[i], t[i - 1]]), rtol=ctx.rtol, atol=ctx.atol,
+                # which tensors of the augmented state the controller sees (Appendix D.3).  The solver zips its
+                # tolerance lists with the state tuple, so the LENGTH of the lists is the switch: n = the forward
+                # state only (what CNF's lists do, 'state_only'), 2n = + the per-row adjoints ('rows', the kernels'
+                # CNF_FLAG_ADJ_CONTROL_ALL), 2n + 2 = everything, as scalar tolerances would ('all')
+                n_ctl = {"state_only": None, "rows": 2 * n, "all": 2 * n + 2}[ctx.control]
+                b_rtol, b_atol = ctx.rtol, ctx.atol
+                if n_ctl is not None:
+                    b_rtol = [_as_list(ctx.rtol, 1)[0]] * n_ctl
+                    b_atol = [_as_list(ctx.atol, 1)[0]] * n_ctl
+                sol = odeint(augmented, aug0, torch.stack([t[i], t[i - 1]]), rtol=b_rtol, atol=b_atol,
                              method=ctx.method,
                              options=dict(ctx.options or {}, stats=ctx.stats.setdefault("backward", {})))
                 adj_y = tuple(s[1] + g[i - 1] for s, g in zip(sol[n:2 * n], grad_out))
                 adj_t, adj_p = sol[2 * n][1], sol[2 * n + 1][1]
             time_grads.append(adj_t.reshape(1))
-        return (None, None, torch.cat(time_grads[::-1]), None, None, None, None, None, adj_p) + adj_y
+        return (None, None, torch.cat(time_grads[::-1]), None, None, None, None, None, None, adj_p) + adj_y
 
 
-def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None, stats=None):
+def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None, stats=None,
+                   adjoint_control="state_only"):
     """`odeint` whose backward integrates the adjoint ODE instead of differentiating the solver.
 
     `func` must be an nn.Module (its parameters receive gradients).  `stats` (a dict) receives the
-    forward / backward step counters.
+    forward / backward step counters.  `adjoint_control`: 'state_only' (default: the tolerances as passed, i.e. for
+    CNF's length-2 lists error control over the forward state only), 'rows' (+ the adjoints of the state tensors) or
+    'all' (+ the time and parameter adjoints) -- see _Adjoint.backward.  For 'rows' / 'all' the initial-step heuristic
+    runs over the same tensors with the original's arithmetic: the adjoint of logp has identically zero dynamics, so
+    its d0 / d1 is infinite, h0 = inf, the second evaluation sees a non-finite state, and python's max() -- which skips
+    NaNs that are not its first argument -- leaves (0.01 / max(d1))^(1/5) as the first step.
     """
+    assert adjoint_control in ("state_only", "rows", "all"), adjoint_control
     assert isinstance(func, torch.nn.Module), "func must be an nn.Module (parameters are needed)"
     single = torch.is_tensor(y0)
     if single:
@@ -383,5 +400,5 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
     flat_params = _flat([p for p in func.parameters() if p.requires_grad],
                         [p for p in func.parameters() if p.requires_grad])
     stats = {} if stats is None else stats
-    sol = _Adjoint.apply(func, len(y0), t, rtol, atol, method, options, stats, flat_params, *y0)
+    sol = _Adjoint.apply(func, len(y0), t, rtol, atol, method, options, stats, adjoint_control, flat_params, *y0)
     return sol[0] if single else sol

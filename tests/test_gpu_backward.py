@@ -236,6 +236,84 @@ def test_solve_bwd_stiff_trained_field(dim, spread, train):
     print("   grad_theta |hip-f64| %.2e |oracle-f64| %.2e (scale %.2e); worst block ratio hip/oracle %.2f" % (e_h, e_o, sp, worst))
 
 
+@pytest.mark.parametrize("case,rows,spread,zero_al", [
+    ("rand_d2", 2048, False, False), ("rand_d2", 2048, True, False), ("rand_d1", 64, False, False),
+    ("rand_d2", 4200, False, False), ("rand_d16_hutch", 512, False, False), ("rand_d16_hutch", 2048, True, False),
+    ("rand_h256", 200, False, False), ("rand_d2", 300, False, True), ("stiff_d2", 0, True, False)])
+def test_adjoint_control_all_matches_oracle(case, rows, spread, zero_al):
+    """CNF_FLAG_ADJ_CONTROL_ALL (SURVEY.md Appendix D.3's switch): a_z and a_logp under the adjoint solve's step control.
+    Against the oracle's odeint_adjoint(adjoint_control='rows') -- tolerance lists as long as (z, logp, a_z, a_logp) --
+    in every adjoint kernel family: identical step counts and the usual gradient bar on the random-init fields; on the
+    stiff trained field -- with the cotangents of the SUMMED loss (rows x those of the mean), so that a_z is large against
+    atol and its error ratio decides: ~75 % more attempts than state_only -- the 3 % band around the oracle's count of THAT
+    mode, and gradients no further from float64 than 2x the oracle's.  zero_al: cotangent of logp identically zero (a_logp's d0 / d1 is then 0 / 0 instead of inf: the heuristic's
+    ordinary branch with the a_z terms).  Parity unpinned in both modes (no reference artefact holds backward NFE)."""
+    nat = _native()
+    g = torch.Generator().manual_seed(29)
+    hutch = case.endswith("hutch")
+    hidden = 256 if "h256" in case else 64
+    if case == "stiff_d2":
+        m, x, gold, _ = _stiff_case(2)
+        dim, rows = 2, x.shape[0]
+    else:
+        dim = 16 if "d16" in case else (1 if "d1" in case else 2)
+        kw = dict(hidden_dims=(256, 256, 256)) if hidden == 256 else {}
+        m = oracle_random_model(dim, seed=7, divergence_fn="approximate" if hutch else "brute_force", scale=2.0 if hidden == 64 else 1.5, **kw)
+        x = torch.randn(rows, dim, generator=g)
+    e = torch.randn(rows, dim, generator=g) if hutch else None
+    m.train()
+    fn = _odefunc(m)
+    if hutch:
+        orig = fn.before_odeint
+        fn.before_odeint = lambda e_=None: orig(e=e)
+    blk = m.chain[0]
+    cot = float(rows) if case == "stiff_d2" else 1.0   # cotangent scale: 1 = mean loss, rows = summed loss
+
+    def oracle_run(mode):
+        blk.adjoint_error_control = mode
+        m.zero_grad()
+        xx = x.clone().requires_grad_(True)
+        z, dl = m(xx, torch.zeros(rows, 1))
+        loss = -oracle.standard_normal_logprob(z).sum(1, keepdim=True).mean() if zero_al else _loss(z, dl)
+        (loss * cot).backward()
+        gp = torch.cat([p.grad.reshape(-1) for p in fn.diffeq.parameters()])
+        return xx.grad.clone(), gp, dict(blk.stats["backward"])
+
+    try:
+        gx_ref, gp_ref, bo = oracle_run("rows")
+        _, _, bo_state = oracle_run("state_only") if case == "stiff_d2" else (None, None, None)
+    finally:
+        blk.adjoint_error_control = "state_only"
+    T = float(blk.sqrt_end_time.detach() * blk.sqrt_end_time.detach())
+    net = nat.net_desc(dim, hidden, 3, hutch)
+    params = _flat(m).to(DEV)
+    opts = nat.make_opts("dopri5", 1e-5, 1e-5, flags=nat.FLAG_ADJ_CONTROL_ALL | (nat.FLAG_SPREAD if spread else 0))
+    ed = None if e is None else e.to(DEV)
+    z1, l1, s_f = nat.solve_fwd(net, params, x.to(DEV), None, 0.0, T, opts, ed)
+    gl1 = torch.zeros(rows, 1, device=DEV) if zero_al else torch.full((rows, 1), cot / rows, device=DEV)
+    gx, gl0, gp, s_b = nat.solve_bwd(net, params, z1, l1, z1 * (cot / rows), gl1, 0.0, T, opts, ed)
+    torch.cuda.synchronize()
+    s_b = nat.Stats(s_b)
+    s_b.raise_for_status()
+    e_gx, e_gp = rel_err(gx, gx_ref), rel_err(gp, gp_ref)
+    print("adjoint control ALL %s rows=%d spread=%d zero_al=%d: bwd steps hip %d+%d oracle('rows') %d+%d first dt %.5g | rel err grad_x "
+          "%.2e grad_theta %.2e" % (case, rows, spread, zero_al, s_b.n_accepted, s_b.n_rejected, bo["n_accepted"], bo["n_rejected"],
+                                    bo["dts"][0], e_gx, e_gp))
+    assert s_b.nfe == 2 + 6 * (s_b.n_accepted + s_b.n_rejected)
+    if case == "stiff_d2":
+        n_b, n_bo = s_b.n_accepted + s_b.n_rejected, bo["n_accepted"] + bo["n_rejected"]
+        n_state = bo_state["n_accepted"] + bo_state["n_rejected"]
+        print("   oracle('state_only') attempts %d" % n_state)
+        assert abs(n_b - n_bo) <= 0.03 * n_bo
+        assert n_bo > 1.3 * n_state        # the switch does something here
+        gx64, gp64 = gold["grad_x"] * cot, gold["grad_theta"] * cot
+        assert (gx.cpu().double() - gx64).abs().max() <= 2.0 * max((gx_ref.double() - gx64).abs().max().item(), 2e-5 * gx64.abs().max().item())
+        assert (gp.cpu().double() - gp64).abs().max() <= 2.0 * max((gp_ref.double() - gp64).abs().max().item(), 2e-5 * gp64.abs().max().item())
+    else:
+        assert (s_b.n_accepted, s_b.n_rejected) == (bo["n_accepted"], bo["n_rejected"])
+        assert e_gx < 2e-4 and e_gp < 2e-4
+
+
 def test_module_training_step_fills_parameter_grads():
     from gan_flow_amd import gu_ffjord
     mo = oracle_random_model(2, seed=11, scale=1.5)

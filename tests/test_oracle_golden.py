@@ -146,3 +146,41 @@ def test_adjoint_gradients_match_autograd_through_unrolled_rk4():
     loss_of(zs[1], ls[1]).backward()
     g_bp = torch.cat([p.grad.reshape(-1) for p in blk.odefunc.parameters()])
     assert (g_adj - g_bp).abs().max() / g_bp.abs().max() < 1e-5
+
+
+def test_adjoint_error_control_modes():
+    """SURVEY Appendix D.3's switch in the oracle: 'state_only' (CNF's length-2 tolerance lists, zipped with the state
+    tuple), 'rows' (+ a_z, a_logp; the kernels' CNF_FLAG_ADJ_CONTROL_ALL) and 'all' (+ a_t, a_theta; what scalar tolerances
+    would do).  All three integrate the same adjoint ODE: gradients agree to solver accuracy; what changes is the step
+    sequence.  For 'rows' / 'all' the initial-step heuristic meets a_logp's identically-zero dynamics (d0 / d1 = inf) and,
+    with python's NaN-skipping max(), leaves (0.01 / max d1)^(1/5) as the first step -- checked here against that formula.
+    Parity unpinned: no file of the reference records backward step counts."""
+    torch.manual_seed(2)
+    m = oracle.build_cnf(2).train()
+    blk = m.chain[0]
+    x = torch.randn(64, 2)
+    grads, stats = {}, {}
+    for mode in ("state_only", "rows", "all"):
+        blk.adjoint_error_control = mode
+        m.zero_grad()
+        z, dl = m(x, torch.zeros(64, 1))
+        (-(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()).backward()
+        grads[mode] = torch.cat([p.grad.reshape(-1) for p in blk.odefunc.parameters()])
+        stats[mode] = dict(blk.stats["backward"])
+    for mode in ("rows", "all"):
+        assert (grads[mode] - grads["state_only"]).abs().max() < 2e-4 * grads["state_only"].abs().max()
+        assert stats[mode]["n_accepted"] >= stats["state_only"]["n_accepted"]
+    # first step of 'rows': (0.01 / max(d1z, d1l, d1a))^(1/5), scales atol + rtol |y|, rms over each tensor
+    with torch.no_grad():
+        z1, dl1 = z.detach(), dl.detach()
+        a_z, a_l = z1 / 64, torch.full((64, 1), 1.0 / 64)
+    fn = blk.odefunc
+    fn.before_odeint()
+    with torch.enable_grad():
+        zz = z1.clone().requires_grad_(True)
+        f, nd = fn(torch.tensor(0.5), (zz, dl1.clone().requires_grad_(True)))
+        vz, = torch.autograd.grad((f, nd), zz, (-a_z, -a_l))
+    rms = lambda v, y: float((v / (1e-5 + 1e-5 * y.abs())).pow(2).mean().sqrt())   # noqa: E731
+    d1 = max(rms(-f.detach(), z1), rms(-nd.detach(), dl1), rms(-vz, a_z))   # reversed time: slopes change sign
+    assert abs(stats["rows"]["dts"][0] - (0.01 / d1) ** 0.2) < 1e-5 * stats["rows"]["dts"][0]
+    assert stats["rows"]["dts"][0] != stats["state_only"]["dts"][0]
