@@ -644,7 +644,11 @@ __device__ __forceinline__ double next_step_size(double dt, float worst) {
     const double inv_dfactor = worst < 1.f ? 1.0 : 5.0;
     const double root = (double)sqrtf(worst);
     // outside [1e-30, 1e30] the factor is clamped anyway (0.1 below, inv_dfactor above): no need for a root there
+#ifdef CNF_EXP_POW_STEP   // experiment: the library's double-precision pow(), as round 1 had it (DESIGN.md section 4, 3-wave build)
+    const double r5 = pow(root, 0.2);
+#else
     const double r5 = root < 1e-30 ? 0.0 : (root > 1e30 ? 1e6 : fifth_root(root));
+#endif
     const double factor = fmax(0.1, fmin(r5 / 0.9, inv_dfactor));
     return dt / factor;
 }
