@@ -827,6 +827,70 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
     return red.status == 0;
 }
 
+// The same reduction in two halves, for callers that have work to do while the granules travel: wg_reduce_publish sums the
+// workgroup's partials and stores its granules; wg_reduce_collect polls and totals.  Arithmetic and summation order are those
+// of wg_allreduce4 (bit-identical totals).  red.part must stay untouched in between, and no other reduction may run.
+// All threads of the workgroup call both.
+template <bool ALLQ = false>
+__device__ inline void wg_reduce_publish(GridSync& gs, RedLds& red, double (&v)[4], int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ALLQ ? xq_sum_f64(row16_sum(v[i])) : row16_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red.part[w][i] = v[i];
+    }
+    __syncthreads();
+    if (gs.nwg > 1) {
+        gs.epoch += 1;
+        if (w == 0 && lane < 4) {
+            const double s = red.part[0][lane] + red.part[1][lane] + red.part[2][lane] + red.part[3][lane];
+            unsigned long long* bank = gs.gran + (size_t)(gs.epoch & 1u) * (size_t)(gs.nwg * 4);
+            const unsigned long long pk = ((unsigned long long)gs.epoch << 32) | (unsigned long long)__float_as_uint((float)s);
+            __hip_atomic_store(bank + blockIdx.x * 4 + lane, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ inline bool wg_reduce_collect(GridSync& gs, RedLds& red, double (&v)[4], int w, int lane) {
+    if (w == 0) {
+        double s = 0.0;
+        if (lane < 4) s = red.part[0][lane] + red.part[1][lane] + red.part[2][lane] + red.part[3][lane];
+        if (gs.nwg > 1) {
+            const unsigned long long* bank = gs.gran + (size_t)(gs.epoch & 1u) * (size_t)(gs.nwg * 4);
+            const int ng = gs.nwg * 4;
+            double acc = 0.0;
+            bool done = false;
+            constexpr int kPerLane = kMaxWG * 4 / 64;
+            for (unsigned spin = 0; spin < kSpinLimit; ++spin) {
+                unsigned long long x[kPerLane];
+#pragma unroll
+                for (int k = 0; k < kPerLane; ++k) {
+                    const int g = lane + 64 * k;
+                    x[k] = g < ng ? __hip_atomic_load(bank + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : ((unsigned long long)gs.epoch << 32);
+                }
+                bool ok = true;
+                acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < kPerLane; ++k) {
+                    ok &= (unsigned)(x[k] >> 32) == gs.epoch;
+                    acc += (double)__uint_as_float((unsigned)x[k]);
+                }
+                if (__all(ok)) { done = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!done && lane == 0) red.status = CNF_ERR_SYNC_TIMEOUT;
+            acc += dpp_mov_f64<0x124>(acc);
+            acc += dpp_mov_f64<0x128>(acc);
+            s = xq_sum_f64(acc);
+        }
+        if (lane < 4) red.tot[lane] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = red.tot[i];
+    return red.status == 0;
+}
+
 // End of a batch-global kernel: leave the granules as the next launch needs them (all zero) without a memset node.
 // Every workgroup takes a ticket after its last reduction; the one that takes the last ticket knows all the others
 // are done reading, clears both banks and resets the ticket (the word right after the banks).  All threads call it.

@@ -482,13 +482,19 @@ __device__ __forceinline__ void stage_bwd_net(BwdNet<D>& net, SplitBwdLds<D>& sb
 // one augmented evaluation; same mathematics as aug_eval (cnf_bwd.hip), each wave on its own feature tile
 // acc / alt: the accumulators of the hidden matrices' outer products; to_alt (uniform) sends this evaluation's to `alt`
 // (the FSAL buffer), so that no register block has to be copied around the call.
-template <int D, bool HUTCH, class WS, int NL>
+// mid(f, div): called by all threads once the forward half is done (f and div are final, the reverse sweep has not begun):
+// the solve kernel starts its grid-wide reduction there, so that the granules travel while the sweep runs.
+struct NoMid {
+    template <class F>
+    __device__ __forceinline__ void operator()(const F&, float) const {}
+};
+template <int D, bool HUTCH, class WS, int NL, class Mid>
 __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWeightsB16& wb, SplitBwdLds<D>& sb, WS& ws,
                                                BwdXchg<D>& xc, int lane,
                                                int wave, float t, const float (&z)[D], const float (&e)[D],
                                                const float (&az)[D], float al, float w, bool with_theta, float (&f)[D],
                                                float& div, float (&vz)[D], BigAccT<NL>& acc, BigAccT<NL>& alt, bool to_alt,
-                                               int small_base, int part, Prof& pr) {
+                                               int small_base, int part, Prof& pr, Mid&& mid) {
     constexpr bool B16 = kBwdB16<D>;
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
@@ -602,19 +608,12 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
         }
     }
     pr.mark(9);
-    __syncthreads();
-    pr.mark(10);
-    float g4[D], u4[D], U4[D];
-    div = 0.f;
+    // The last layer's partial sums meet behind the SAME barrier as the reverse sweep's first exchange: nothing the sweep
+    // needs up to there depends on f or div (its cotangents are -a_z and a_logp), so f, div and the last layer's vector
+    // gradients -- the only consumers of the cross-wave sums -- are formed after that barrier (finish_forward below).
+    float g4[D];
 #pragma unroll
-    for (int m = 0; m < D; ++m) {
-        g4[m] = ws.gate4[0][m];
-        u4[m] = sum4(xc.part[0][m][j], xc.part[1][m][j], xc.part[2][m][j], xc.part[3][m][j]);
-        U4[m] = sum4(xc.part[0][D + m][j], xc.part[1][D + m][j], xc.part[2][D + m][j], xc.part[3][D + m][j]);
-        f[m] = fmaf(g4[m], u4[m], ws.gate4[1][m]);
-        const float dm = g4[m] * U4[m];
-        div += HUTCH ? dm * e[m] : dm;
-    }
+    for (int m = 0; m < D; ++m) g4[m] = ws.gate4[0][m];
 
     // ------------------------------------------------------------------ reverse sweep (own tile)
     float lf[D];
@@ -655,6 +654,18 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                 if (kind < 2 && m + kind < D) lds_add(&small[SI::l4 + (m + kind) * kH + fo + qq], w * (kind == 0 ? ta : tb));
             }
         }
+    }
+    auto finish_forward = [&]() {   // behind the first barrier of the sweep
+        float u4[D], U4[D];
+        div = 0.f;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            u4[m] = sum4(xc.part[0][m][j], xc.part[1][m][j], xc.part[2][m][j], xc.part[3][m][j]);
+            U4[m] = sum4(xc.part[0][D + m][j], xc.part[1][D + m][j], xc.part[2][D + m][j], xc.part[3][D + m][j]);
+            f[m] = fmaf(g4[m], u4[m], ws.gate4[1][m]);
+            const float dm = g4[m] * U4[m];
+            div += HUTCH ? dm * e[m] : dm;
+        }
         if (th_hi) {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
@@ -666,7 +677,8 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                 if (wave == 0 && lane < 4) lds_add(&small[SI::l4 + kH * D + qq * D + m], w * fac * val);
             }
         }
-    }
+        mid(f, div);
+    };
 
     pr.mark(12);
     // dW[16*wave + i'][:] += sum_rows (w ubar)[i'][row] * x_in[:][row] of hidden layer lc (K = the 16 rows).  Nothing on
@@ -792,6 +804,7 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                 }
             }
             __syncthreads();
+            if (l == 1) finish_forward();
             pr.mark(l == 1 ? 14 : 17);
             // cotangent of this layer's input, own input-feature tile: (W^T ubar)[16*wave ..]
             f32x4 o4[NS];
@@ -961,7 +974,7 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
     BigAccS acc;
     acc.zero();
     Prof pr;
-    aug_eval_split<D, HUTCH>(net, wb, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc, acc, false, 0, 0, pr);
+    aug_eval_split<D, HUTCH>(net, wb, sb, wl[kShareWaveLds<D> ? 0 : w], xc, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, acc, acc, false, 0, 0, pr, NoMid{});
     #pragma unroll
     for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
         f[m] = fmaf(-res, zz[m], f[m]);
@@ -1046,7 +1059,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     int phase = PH_F0, stage = 0;
     int nacc = 0, nrej = 0, status = 0, nrun = 0;
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
-    float sc[CE];
+    float sc[CE];   // scale of the initial-step heuristic (the solve's initial state)
+#pragma unroll
+    for (int c = 0; c < CE; ++c) sc[c] = atol + fabsf(y0[c]) * rtol;
     constexpr bool FSAL = kFsalTheta<D>;
     BigAccT<NL> acc, gfirst, glast, total;   // acc: the attempt's weighted sums; gfirst / glast: see kFsalTheta; total: RUNTOT
     acc.zero();
@@ -1079,8 +1094,52 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         const bool to_alt = FSAL && (to_first || to_last);
         const int small = to_alt ? (to_first ? i_first : i_last) * SmallIdxS<D>::padded : 0;
         pr.mark(0);
+        // The controller's sums over (z, logp) -- the initial-step norms, or the error ratios of a finished attempt -- from
+        // the slopes kc of THIS evaluation.  They need f and div only, which are final when the evaluation's forward half
+        // is: the grid-wide reduction is started from there (mid, below) and collected after the reverse sweep, so the
+        // granules' trip through the fabric (~3 us) is hidden behind half an evaluation.  Same sums, same order, same
+        // bits as reducing afterwards.  (CNF_FLAG_ADJ_CONTROL_ALL needs a_z's slope too: it reduces after the sweep.)
+        auto control_sums = [&](const float (&kc)[CE], double (&S)[4]) {
+#pragma unroll
+            for (int c = 0; c < CE; ++c) {
+                if (phase == PH_F0) {
+                    const float u = y0[c] / sc[c], v = kc[c] / sc[c];
+                    if (counted) {
+                        S[c < D ? 0 : 1] += (double)u * u;
+                        S[c < D ? 2 : 3] += (double)v * v;
+                    }
+                } else if (phase == PH_F1) {
+                    const float u = (kc[c] - ws.kst[0][c][j]) / sc[c];
+                    if (counted) S[c < D ? 0 : 1] += (double)u * u;
+                } else {
+                    float err = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                    err += (dtf * kCErr[6]) * kc[c];
+                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(yi[c]));   // yi: the candidate y1
+                    const float u = err / tol;
+                    if (counted) {
+                        S[c < D ? 0 : 1] += (double)u * u;
+                        if (!isfinite(y0[c])) S[2] += 1.0;
+                    }
+                }
+            }
+            if (phase == PH_F1 && nll && counted) S[2] = (double)nll_row;
+        };
+        bool early = false;   // this evaluation's reduction is already under way (uniform)
+        auto mid = [&](const float (&f_)[D], float div_) {
+            if (a.adj_all || (phase == PH_STAGE && stage != 6)) return;
+            float kc[CE];
+#pragma unroll
+            for (int m = 0; m < D; ++m) kc[m] = sgn * fmaf(-res, zz[m], f_[m]);
+            kc[D] = -sgn * (div_ - res * (float)D);
+            double S[4] = {0, 0, 0, 0};
+            control_sums(kc, S);
+            wg_reduce_publish(gs, red, S, w, lane);
+            early = true;
+        };
         aug_eval_split<D, HUTCH>(net, wb, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc, glast,
-                                 to_alt, small, part, pr);
+                                 to_alt, small, part, pr, mid);
         #pragma unroll
         for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
             f[m] = fmaf(-res, zz[m], f[m]);
@@ -1100,18 +1159,16 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         if (phase == PH_F0) {
             double S[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < CE; ++c) {
-                ws.kst[0][c][j] = k[c];
-                sc[c] = atol + fabsf(y0[c]) * rtol;
-                const float u = y0[c] / sc[c], v = k[c] / sc[c];
-                if (counted) {
-                    S[c < D ? 0 : 1] += (double)u * u;
-                    S[c < D ? 2 : 3] += (double)v * v;
-                }
-            }
+            for (int c = 0; c < C; ++c) ws.kst[0][c][j] = k[c];
+            if (early) {
+                if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            } else {
+                float kc[CE];
 #pragma unroll
-            for (int c = CE; c < C; ++c) ws.kst[0][c][j] = k[c];
-            if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                for (int c = 0; c < CE; ++c) kc[c] = k[c];
+                control_sums(kc, S);
+                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            }
             const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
             d1z = (float)sqrt(S[2] / nz);
             d1l = (float)sqrt(S[3] / nl);
@@ -1136,21 +1193,23 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         }
         if (phase == PH_F1) {
             double S[4] = {0, 0, 0, 0};
+            if (early) {
+                if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            } else {
+                float kc[CE];
 #pragma unroll
-            for (int c = 0; c < CE; ++c) {
-                const float u = (k[c] - ws.kst[0][c][j]) / sc[c];
-                if (counted) S[c < D ? 0 : 1] += (double)u * u;
-            }
-            if (nll && counted) S[2] = (double)nll_row;
-            if (a.adj_all && counted) {
+                for (int c = 0; c < CE; ++c) kc[c] = k[c];
+                control_sums(kc, S);
+                if (a.adj_all && counted) {
 #pragma unroll
-                for (int m = 0; m < D; ++m) {
-                    const int c = D + 1 + m;
-                    const float u = (k[c] - ws.kst[0][c][j]) / (atol + fabsf(y0[c]) * rtol);
-                    S[3] += (double)u * u;
+                    for (int m = 0; m < D; ++m) {
+                        const int c = D + 1 + m;
+                        const float u = (k[c] - ws.kst[0][c][j]) / (atol + fabsf(y0[c]) * rtol);
+                        S[3] += (double)u * u;
+                    }
                 }
+                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
-            if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * inv_rows);
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
             const float d2a = (float)sqrt(S[3] / nz) / h0;
@@ -1165,31 +1224,27 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                 double S[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int c = 0; c < C; ++c) y1[c] = yi[c];
-#pragma unroll
-                for (int c = 0; c < CE; ++c) {
-                    float err = 0.f;
-#pragma unroll
-                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
-                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c]));
-                    const float u = err / tol;
-                    if (counted) {
-                        S[c < D ? 0 : 1] += (double)u * u;
-                        if (!isfinite(y0[c])) S[2] += 1.0;
-                    }
-                }
-                if (a.adj_all) {   // a_z under error control as well
-#pragma unroll
-                    for (int m = 0; m < D; ++m) {
-                        const int c = D + 1 + m;
-                        float err = 0.f;
-#pragma unroll
-                        for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
-                        const float u = err / (atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c])));
-                        if (counted) S[3] += (double)u * u;
-                    }
-                }
                 pr.mark(21);
-                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (early) {
+                    if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                } else {
+                    float kc[CE];
+#pragma unroll
+                    for (int c = 0; c < CE; ++c) kc[c] = k[c];
+                    control_sums(kc, S);
+                    if (a.adj_all) {   // a_z under error control as well
+#pragma unroll
+                        for (int m = 0; m < D; ++m) {
+                            const int c = D + 1 + m;
+                            float err = 0.f;
+#pragma unroll
+                            for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                            const float u = err / (atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c])));
+                            if (counted) S[3] += (double)u * u;
+                        }
+                    }
+                    if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                }
                 pr.mark(22);
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
                 const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
