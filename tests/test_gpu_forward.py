@@ -19,7 +19,7 @@ import pytest
 import torch
 
 import oracle
-from _helpers import appendix_c, oracle_fixture_model, oracle_random_model, product_like, rel_err
+from _helpers import appendix_c, oracle_fixture_model, oracle_random_model, product_like, rel_err, elem_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -68,6 +68,12 @@ def test_field_matches_oracle(dim, hutch, rows):
         f, nd = nat.eval_field(net, params, t, z.to(DEV), None if e is None else e.to(DEV))
         assert rel_err(f, f_ref) < 1e-5
         assert rel_err(nd, nd_ref) < 2e-5
+        # every element in its OWN scale (down to 1 % of the largest: below that an fp32 sum of O(max) terms carries no
+        # relative information): the max-norm ratios above cannot see a small element that is far off
+        pe_f, pe_d = elem_err(f, f_ref, floor=1e-2), elem_err(nd, nd_ref, floor=1e-2)
+        print("field d=%d t=%.2f: max-norm rel err f %.1e -div %.1e | per-element (floor 1%% of max) f %.1e -div %.1e"
+              % (dim, t, rel_err(f, f_ref), rel_err(nd, nd_ref), pe_f, pe_d))
+        assert pe_f < 1e-4 and pe_d < 2e-4
 
 
 def _solve_pair(m, x, reverse, solver, device_model=None, step_size=None, tile_rows=0, hutch=False, e=None):
@@ -173,6 +179,9 @@ def test_rk4_parity_random(dim, hutch, rows):
     (z_ref, l_ref, _), (z, l, st) = _solve_pair(m, x, False, "rk4", step_size=0.05, hutch=hutch, e=e)
     assert rel_err(z, z_ref) < 1e-5
     assert rel_err(l, l_ref) < 1e-5
+    pe_z, pe_l = elem_err(z, z_ref, floor=1e-2), elem_err(l, l_ref, floor=1e-2)
+    print("rk4 d=%d rows=%d: per-element rel err (floor 1%% of max) z %.1e logp %.1e" % (dim, rows, pe_z, pe_l))
+    assert pe_z < 1e-4 and pe_l < 1e-4   # every row in its own scale, not only against the largest element
 
 
 def test_rk4_single_step_default_grid():
@@ -299,10 +308,20 @@ def test_dopri5_tile_local_control_matches_oracle_per_tile(which):
     else:
         assert abs(st.nfe - nfe_max) <= 0.03 * nfe_max and abs(st.row_evals - row_evals) <= 0.03 * row_evals
     assert mz_h <= 2 * mz_o + 1e-5 and ml_h <= 2 * ml_o + 1e-5
-    if which == "unimodal":
-        assert ez_h <= 2 * ez_o + 1e-4 and el_h <= 2 * el_o + 1e-4
-    else:
-        assert ez_h < 1e-3 and el_h < 1e-1
+    # the error DISTRIBUTION over the 70 rows against the oracle's own (both measured against float64): median and 90th
+    # percentile within 2x of the oracle's at the same quantile; the worst row within 3x of the oracle's worst row of
+    # THIS sample or, where a flipped accept/reject decision in one tile moves a single row, within the worst-row error
+    # dopri5(1e-5) shows on 2048 rows of the field with either arithmetic (tools/dbg_tile_local_accuracy.py: z 4e-4 on
+    # both fields, logp 3.7e-3 / 4.4e-2; bars: those figures + a third)
+    qs = torch.tensor([0.5, 0.9], dtype=torch.float64)
+    wz, wl = 5.5e-4, (5e-3 if which == "unimodal" else 6e-2)
+    for name, e_h, e_o, floor in (("z", (z.cpu().double() - z64).abs(), (zo.double() - z64).abs(), 1e-5),
+                                  ("logp", (l.cpu().double() - l64).abs(), (lo_.double() - l64).abs(), 1e-4)):
+        q_h, q_o = torch.quantile(e_h.flatten(), qs), torch.quantile(e_o.flatten(), qs)
+        print("   %s error percentiles (50, 90, max): hip %.2e %.2e %.2e | oracle %.2e %.2e %.2e"
+              % (name, q_h[0], q_h[1], e_h.max(), q_o[0], q_o[1], e_o.max()))
+        assert bool((q_h <= 2 * q_o + floor).all()), (name, q_h, q_o)
+        assert e_h.max() <= max(3 * e_o.max().item() + floor, wz if name == "z" else wl), (name, e_h.max(), e_o.max())
 
 
 @pytest.mark.parametrize("hutch", [False, True])
@@ -384,13 +403,30 @@ def test_round_trip_large_batch_property():
         print("round trip tile=%d: %s | %s | max dz %.2e mean %.2e max dlogp %.2e"
               % (tile, s1, s2, (zb - z0).abs().max().item(), (zb - z0).abs().mean().item(), lb.abs().max().item()))
         assert x.min() > -5 and x.max() < 95
-        # dopri5(1e-5) itself is ~4e-2 off in logp on this stiff model, and its embedded error estimate is unreliable
-        # where the trained density has near-jumps (uniform-component edges): three legitimate fp32 runs of the SAME 16
-        # rows (CPU oracle, this kernel with per-tile and with batch-global control) took 108+60 / 106+56 / 112+67
-        # attempts and left logp residuals of 4e-2 / 0.88 / 8e-3 on the one row that crosses such an edge.  So the
-        # bar is on the bulk (mean, 99.9th percentile), with a loose sanity bound on the single worst row.
-        assert (zb - z0).abs().max() < 2e-2 and (zb - z0).abs().mean() < 1e-3
-        assert lb.abs().mean() < 1e-2 and torch.quantile(lb.abs().flatten(), 0.999) < 0.15 and lb.abs().max() < 3.0
+        # dopri5(1e-5) itself is ~4e-2 off in logp on this stiff model (its embedded error estimate is unreliable where the
+        # trained density has near-jumps), so the bar is the ORACLE's own round-trip residual distribution under the same
+        # control -- per tile on the first 256 rows, batch-global on the first 1024 (CPU seconds) -- quantile by
+        # quantile: 50th / 90th / 99th percentile of the 16384 rows within 1.5x of the oracle's, the 99.9th within 6x of the
+        # oracle's 99th (the oracle's sample is too small for its own 99.9th; the tail is a handful of rows next to the density's
+        # near-jumps and moves by 20 % with the last bit of T), and an absolute bound on the worst row
+        # (measured: z 5e-4 / 3.6e-3, logp 0.09 / 0.13 for batch-global / per-tile control; oracle maxima 1.2e-3, 0.06).
+        with torch.no_grad():
+            if tile:
+                rt = [m(*m(z0[lo:lo + 16].cpu().clone(), torch.zeros(16, 1), reverse=True)) for lo in range(0, 256, 16)]
+                dz_o = torch.cat([zb_ - z0[lo:lo + 16].cpu() for (zb_, _), lo in zip(rt, range(0, 256, 16))]).abs()
+                dl_o = torch.cat([lb_ for _, lb_ in rt]).abs()
+            else:
+                zb_, lb_ = m(*m(z0[:1024].cpu().clone(), torch.zeros(1024, 1), reverse=True))
+                dz_o, dl_o = (zb_ - z0[:1024].cpu()).abs(), lb_.abs()
+        qs = torch.tensor([0.5, 0.9, 0.99, 0.999], dtype=torch.float64)
+        for name, e_h, e_o, floor, worst in (("z", (zb - z0).abs().cpu().double(), dz_o.double(), 2e-6, 2e-2),
+                                             ("logp", lb.abs().cpu().double(), dl_o.double(), 2e-4, 0.5)):
+            q_h, q_o = torch.quantile(e_h.flatten(), qs), torch.quantile(e_o.flatten(), qs)
+            print("   %s residual percentiles (50, 90, 99, 99.9, max): hip %s | oracle %s"
+                  % (name, " ".join("%.2e" % v for v in q_h.tolist() + [e_h.max().item()]),
+                     " ".join("%.2e" % v for v in q_o.tolist() + [e_o.max().item()])))
+            assert bool((q_h[:3] <= 1.5 * q_o[:3] + floor).all()), (name, q_h, q_o)
+            assert q_h[3] <= 6 * q_o[2] + floor and e_h.max() < worst, (name, q_h, q_o, e_h.max())
 
 
 @pytest.mark.parametrize("hidden", [64, 256])
