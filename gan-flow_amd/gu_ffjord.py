@@ -367,10 +367,18 @@ class ConcurrentTrials:
         replay_ms(cands[:1])
         one = min(replay_ms(cands[:1]) for _ in range(2))
         chosen = [cands[0]]
+        import os
+        import sys
+        verbose = bool(os.environ.get("CNF_DEBUG_STREAMS"))
+        if verbose:
+            print("[ConcurrentTrials] one replay %.3f ms" % one, file=sys.stderr)
         for c in cands[1:]:
             if len(chosen) == n:
                 break
-            if all(min(replay_ms([s, c]) for _ in range(2)) < 1.35 * one for s in chosen):
+            times = [min(replay_ms([s, c]) for _ in range(2)) for s in chosen]
+            if verbose:
+                print("[ConcurrentTrials] candidate with chosen: %s ms" % ["%.3f" % t for t in times], file=sys.stderr)
+            if all(t < 1.35 * one for t in times):
                 chosen.append(c)
         return chosen if len(chosen) == n else None
 
