@@ -115,27 +115,35 @@ template <int D>
 __device__ inline void stage_wimgT16(WimgT16& img, const float* __restrict__ p, int tid) {
     const ParamLayout L = make_layout(D, kH);
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-        // coalesced: a thread reads 4 consecutive floats of a weight row (8 such loads, all in flight at once) and scatters
-        // their pieces as 16-bit stores.  W[i][c]: i = 16 (2 ks + h) + 4 q + r is the k index, c = 16 wv + j' the output
-        unsigned short* img16 = reinterpret_cast<unsigned short*>(&img[0][0][0][0][0][0]);
-        f32x4 v[8];
+        // a thread takes FOUR consecutive rows i of a weight matrix (the k index) and four columns: 4 x 16-byte loads (all
+        // eight of a thread's loads are in flight at once), and the four rows' pieces of one column are 8 adjacent bytes of
+        // the image -- 24 eight-byte LDS stores per thread (16-bit scatter stores: 96).
+        // W[i][c]: i = 16 (2 ks + h) + 4 q + r is the k index, c = 16 wv + j' the output
+        uint2* img64 = reinterpret_cast<uint2*>(&img[0][0][0][0][0][0]);
+        f32x4 v[2][4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = tid + kThreads * k, c4 = e & 15, i = (e >> 4) & 63, l = e >> 10;
-            v[k] = *reinterpret_cast<const f32x4*>(&p[L.w(1 + l) + i * kH + 4 * c4]);
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + kThreads * k, c4 = e & 15, iq = (e >> 4) & 15, l = e >> 8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[k][r] = *reinterpret_cast<const f32x4*>(&p[L.w(1 + l) + (4 * iq + r) * kH + 4 * c4]);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = tid + kThreads * k, c4 = e & 15, i = (e >> 4) & 63, l = e >> 10;
-            const int T = i >> 4, q = (i >> 2) & 3, el = 4 * (T & 1) + (i & 3), ks = T >> 1;
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + kThreads * k, c4 = e & 15, iq = (e >> 4) & 15, l = e >> 8;
+            const int T = iq >> 2, q = iq & 3, ks = T >> 1;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = 4 * c4 + u, lane = 16 * q + (c & 15), wv = c >> 4;
-                uint32_t pc[3];
-                split3_bf16(v[k][u], pc);
+                uint32_t pc[4][3];
 #pragma unroll
-                for (int pi = 0; pi < 3; ++pi)
-                    img16[(((((l * kNW + wv) * 2 + ks) * 3 + pi) * 64 + lane) * 4) * 2 + el] = (unsigned short)(pc[pi] >> 16);
+                for (int r = 0; r < 4; ++r) split3_bf16(v[k][r][u], pc[r]);
+#pragma unroll
+                for (int pi = 0; pi < 3; ++pi) {
+                    uint2 o;
+                    o.x = (pc[0][pi] >> 16) | pc[1][pi];
+                    o.y = (pc[2][pi] >> 16) | pc[3][pi];
+                    img64[((((l * kNW + wv) * 2 + ks) * 3 + pi) * 64 + lane) * 2 + (T & 1)] = o;
+                }
             }
         }
         return;

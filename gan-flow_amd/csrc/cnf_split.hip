@@ -212,19 +212,11 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
-    stage_net(net, a.params, tid);
-    zero_slopes(wl, kNW, tid);
-    __syncthreads();
-    SplitWeightsB16 wb;
-    wb.load(net, w, lane);
     const long row = (long)blockIdx.x * kRows + j;
     const bool counted = row < a.rows && lane < 16 && w == 0;   // every wave carries the same 16 rows: count them once
     const long rr = row < a.rows ? row : a.rows - 1;
-    SplitWaveLds<C>& ws = wl[w];
-
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
-    const double nl = (double)a.rows, nz = nl * D;
-
+    // the rows' inputs and the predecessor's status are requested BEFORE the staging: their round trips to memory overlap it
+    // (a launch's fixed cost is a chain of such round trips: ~1.5 us each at NFE 14, where a solve is only ~50 us long)
     float y0[C], y1[C], yi[C], ee[D];
 #pragma unroll
     for (int m = 0; m < D; ++m) {
@@ -232,6 +224,17 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
         ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
     }
     y0[D] = a.logp0 ? a.logp0[rr] : 0.f;
+    const int after_status = a.after ? a.after->status : 0;
+    stage_net(net, a.params, tid);
+    zero_slopes(wl, kNW, tid);
+    __syncthreads();
+    SplitWeightsB16 wb;
+    wb.load(net, w, lane);
+    SplitWaveLds<C>& ws = wl[w];
+
+    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    const double nl = (double)a.rows, nz = nl * D;
+
 #pragma unroll
     for (int c = 0; c < C; ++c) yi[c] = y0[c];
 
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
 
     Prof pr;
     pr.mark(15);
-    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    status = after_status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
     for (; status == 0;) {
         float zz[D], f[D], div, k[C];
         bool restart = false;
@@ -1008,11 +1011,6 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
-    SplitWeightsB16 wb;
-    stage_bwd_net<D>(net, sb, wb, a.params, tid);
-    zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid);
-    for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += kThreads) (&sb.small[0][0])[i] = 0.f;
-    __syncthreads();
     // kSpreadNote -- a.spread: TWO workgroups per 16-row tile (grid = 2 x tiles, for batches that would leave half the
     // compute units idle).  Both integrate the tile's state identically -- same arithmetic, same totals from the grid
     // reductions, same decisions -- but each keeps only half of the d/dtheta sums (part 1 / part 2, aug_eval_split), which
@@ -1045,6 +1043,13 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     y0[D] = a.logp0[rr];
     nll_row -= y0[D];
     const float al = valid ? (nll ? inv_rows : a.grad_logp1[rr]) : 0.f;
+    const int after_status = a.after ? a.after->status : 0;
+    // staging comes AFTER the loads above were requested: the rows' round trip to memory overlaps it (dopri5_split_kernel)
+    SplitWeightsB16 wb;
+    stage_bwd_net<D>(net, sb, wb, a.params, tid);
+    zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid);
+    for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += kThreads) (&sb.small[0][0])[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < C; ++c) yi[c] = y0[c];
 
@@ -1073,7 +1078,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     Prof pr;
     pr.mark(0);
 
-    if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    status = after_status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
     for (; status == 0;) {
         float zz[D], az[D], f[D], vz[D], div, k[C];
         bool restart = false;
