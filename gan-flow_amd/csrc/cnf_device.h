@@ -768,6 +768,9 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
             const int ng = gs.nwg * 4;
             double acc = 0.0;
             bool done = false;
+#ifdef CNF_PRE_POLL_SLEEP   // experiment: let the store (and the others') travel before the first sweep is issued
+            __builtin_amdgcn_s_sleep(CNF_PRE_POLL_SLEEP);
+#endif
             // every lane polls its granules (g = lane, lane + 64, ...) with ALL loads of a sweep in flight at once: a
             // sweep then costs one L2 round trip instead of one per granule
             constexpr int kPerLane = kMaxWG * 4 / 64;

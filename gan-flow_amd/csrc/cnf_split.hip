@@ -76,19 +76,25 @@ struct alignas(16) SplitXchgBwdB16 {
 template <int D>
 using BwdXchg = typename std::conditional<kBwdB16<D>, SplitXchgBwdB16<D>, SplitXchg<D>>::type;
 
+// The gates of ONE evaluation, own share only: a wave reads the gates of its own 16 features per layer (and the last
+// layer's D), so it computes just those -- lanes 0..47: layer lane >> 4, feature 16 wave + (lane & 15); lanes 48..63: the
+// last layer's entry lane - 48 -- in one pass instead of four (same arithmetic per entry: identical bits).  The LDS
+// layout is unchanged; entries of other waves' features are never read by this wave (with one shared copy, D = 16, the
+// four waves fill it together).
 template <class WS, class N>
-__device__ __forceinline__ void gates_into(const N& n, WS& ws, int lane, float t) {
-#pragma unroll
-    for (int l = 0; l < 3; ++l) {
-        const float g = sigmoid_f(fmaf(n.vec[l][2][lane], t, n.vec[l][3][lane]));
-        ws.gate[l][0][lane] = g;
-        ws.gate[l][1][lane] = fmaf(g, n.vec[l][0][lane], n.vec[l][1][lane] * t);
-    }
-    if (lane < 16) {
-        const float g = sigmoid_f(fmaf(n.vec4[2][lane], t, n.vec4[3][lane]));
-        ws.gate4[0][lane] = g;
-        ws.gate4[1][lane] = fmaf(g, n.vec4[0][lane], n.vec4[1][lane] * t);
-    }
+__device__ __forceinline__ void gates_into(const N& n, WS& ws, int lane, int wave, float t) {
+    const bool last = lane >= 48;
+    const int l = lane >> 4, i = 16 * wave + (lane & 15), m = lane & 15;
+    const float* vw = last ? &n.vec4[2][m] : &n.vec[l][2][i];   // gate weight; bias, layer bias, hyper-bias follow
+    const float* vg = last ? &n.vec4[3][m] : &n.vec[l][3][i];
+    const float* vb = last ? &n.vec4[0][m] : &n.vec[l][0][i];
+    const float* vh = last ? &n.vec4[1][m] : &n.vec[l][1][i];
+    const float g = sigmoid_f(fmaf(*vw, t, *vg));
+    const float c = fmaf(g, *vb, *vh * t);
+    float* og = last ? &ws.gate4[0][m] : &ws.gate[l][0][i];
+    float* oc = last ? &ws.gate4[1][m] : &ws.gate[l][1][i];
+    *og = g;
+    *oc = c;
     wave_lds_fence();
 }
 
@@ -120,7 +126,7 @@ __device__ __forceinline__ void field_fwd_split(const NetLds<D>& n, const SplitW
     constexpr int NS = NT + 1;
     const int q = lane >> 4, j = lane & 15;
     const int fo = 16 * wave + 4 * q;
-    gates_into(n, ws, lane, t);
+    gates_into(n, ws, lane, wave, t);
     pr.mark(1);
     f32x4 act[NS];
     {
@@ -509,7 +515,7 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
     const int q = lane >> 4, j = lane & 15, qq = j & 3;
     const int fo = 16 * wave + 4 * q;
     const int pos = (j & 3) * 4 + (j >> 2);
-    gates_into(n, ws, lane, t);
+    gates_into(n, ws, lane, wave, t);
     pr.mark(1);
     // after reduce8 lane j owns index r* = j & 3 and parameter kind j >> 2 (bias, hyper-bias, gate weight, gate bias):
     // factor = k0 * g + k1 * t + gg * (k2 * t + k3) as arithmetic on lane masks (nested selects compile to branches)
