@@ -833,6 +833,10 @@ template <int D, bool HUTCH>
 static hipError_t launch_solve_bwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRowsPerWG - 1) / kRowsPerWG);
     dbg_timing_begin(s);
+    {
+        const hipError_t res = check_resident(dopri5_bwd_kernel<D, HUTCH>, kThreads, grid);
+        if (res != hipSuccess) return res;
+    }
     hipLaunchKernelGGL((dopri5_bwd_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
     dbg_timing_end(s);
     hipError_t err = hipGetLastError();

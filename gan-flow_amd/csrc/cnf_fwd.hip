@@ -450,6 +450,8 @@ static hipError_t launch_solve_t(const SolveArgs& a, int solver, bool global, hi
     if (solver != CNF_SOLVER_DOPRI5) {
         hipLaunchKernelGGL((rk4_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
     } else if (global) {
+        const hipError_t res = check_resident(dopri5_kernel<D, HUTCH, true, kNW>, kThreads, grid);
+        if (res != hipSuccess) return res;
         hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, true, kNW>), dim3(grid), dim3(kThreads), 0, s, a);
     } else {
         constexpr bool B16 = kEvalB16 && D <= 2;

@@ -44,6 +44,33 @@ hipError_t launch_solve_fwd(int D, bool hutch, const SolveArgs& a, int solver, b
 hipError_t launch_split16_fwd(const SolveArgs& a, hipStream_t s);
 hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s);   // + grad_z1 / grad_x aligned
 
+// Batch-global kernels spin on grid-wide reductions, so every workgroup of the launch must be resident at once.  The API
+// layer bounds the grid by the device's compute-unit count; this asks the runtime what THIS kernel's registers and LDS
+// actually allow (workgroups per compute unit x compute units; cached per kernel and device, so the query runs once, outside
+// any stream capture when the caller warms up first) and rejects a grid that could not be co-resident on an idle device
+// instead of letting it run into the spin limit.  It cannot see other tenants of the GPU: a launch that shares the device
+// with foreign work still ends in CNF_ERR_SYNC_TIMEOUT (bounded spin), not in a hang.
+template <class K>
+inline hipError_t check_resident(K kernel, int threads, int grid) {
+    struct Entry { const void* fn; int dev; int capacity; };
+    static Entry cache[64];
+    static int n_cached = 0;
+    if (grid <= 1) return hipSuccess;
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < n_cached; ++i)
+        if (cache[i].fn == fn && cache[i].dev == dev) return grid <= cache[i].capacity ? hipSuccess : hipErrorCooperativeLaunchTooLarge;
+    int per_cu = 0, cus = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0);
+    if (err == hipSuccess) err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (err != hipSuccess) return err;
+    const int capacity = per_cu * cus;
+    if (n_cached < 64) cache[n_cached++] = Entry{fn, dev, capacity};   // benign race: two threads may both fill an entry
+    return grid <= capacity ? hipSuccess : hipErrorCooperativeLaunchTooLarge;
+}
+
 // diagnostics (cnf_debug_kernel_timing): when enabled, record a HIP event on `s` right before / after a solve kernel
 void dbg_timing_begin(hipStream_t s);
 void dbg_timing_end(hipStream_t s);

@@ -1482,6 +1482,8 @@ hipError_t launch_adam_slabs(const float* slab, int ntiles, int P, int split_at,
 template <int D, bool HUTCH>
 static hipError_t split_fwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
+    hipError_t res = check_resident(dopri5_split_kernel<D, HUTCH>, kThreads, grid);
+    if (res != hipSuccess) return res;
     dbg_timing_begin(s);
     hipLaunchKernelGGL((dopri5_split_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
     dbg_timing_end(s);
@@ -1503,6 +1505,14 @@ hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
 template <int D, bool HUTCH>
 static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
+    hipError_t res = hipSuccess;
+    if constexpr (kFsalTheta<D>) {
+        res = a.spread ? check_resident(dopri5_bwd_split_kernel<D, HUTCH, true>, kThreads, 2 * grid)
+                       : check_resident(dopri5_bwd_split_kernel<D, HUTCH, false>, kThreads, grid);
+    } else {
+        res = check_resident(dopri5_bwd_split_kernel<D, HUTCH, false>, kThreads, a.spread ? 2 * grid : grid);
+    }
+    if (res != hipSuccess) return res;
     dbg_timing_begin(s);
     if constexpr (kFsalTheta<D>) {
         if (a.spread) hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH, true>), dim3(2 * grid), dim3(kThreads), 0, s, a);

@@ -629,6 +629,10 @@ static hipError_t wide_solve_t(const SolveArgs& a, int solver, bool global, hipS
     if (solver != CNF_SOLVER_DOPRI5) {
         hipLaunchKernelGGL((wide_rk4_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
     } else if (global) {
+        {
+            const hipError_t res = check_resident(wide_dopri5_kernel<D, HUTCH, true>, kThreads, grid);
+            if (res != hipSuccess) return res;
+        }
         hipLaunchKernelGGL((wide_dopri5_kernel<D, HUTCH, true>), dim3(grid), dim3(kThreads), 0, s, a);
     } else {
         hipLaunchKernelGGL((wide_dopri5_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
