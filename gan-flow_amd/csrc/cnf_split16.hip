@@ -381,11 +381,14 @@ struct alignas(16) Bwd16Lds {
 // One augmented evaluation.  Cotangents: -a_z on f, a_logp on the divergence estimate.  Outputs f4, div, vz4 =
 // (df/dz)^T(-a_z) + d(a_logp div)/dz (this lane's 4 components); with_theta: adds w * d/dtheta into acc (the two
 // 64 x 64 matrices), gw1 (W1 rows 16 wave + 4q + r, column j), gw4 (W4 rows 4q + r, column 16 wave + j), sb.small.
+// mid(f4, div): called by all threads when the forward half is done (the solve kernel starts its grid reduction there, as
+// dopri5_bwd_split_kernel does: cnf_split.hip)
+template <class Mid>
 __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg16& xc, const f32x4& w1img, const f32x4& w4img,
                                            const f32x4& w1Timg, const f32x4& w4Timg, int lane, int wave, float t,
                                            const f32x4& z4, const f32x4& e4, const f32x4& az4, float al, float w,
                                            bool with_theta, f32x4& f4, float& div, f32x4& vz4, f32x4 (&dw2)[4],
-                                           f32x4 (&dw3)[4], f32x4& gw1, f32x4& gw4, int part, int small_base) {
+                                           f32x4 (&dw3)[4], f32x4& gw1, f32x4& gw4, int part, int small_base, Mid&& mid) {
     // dw2 / dw3: sums for the two 64 x 64 matrices; gw1 / gw4: for W1 / W4.  In the spread kernel a workgroup owns one of
     // each pair and the caller passes the same registers for both (the unowned one is never touched: th_hi / th_lo)
     float* const small = &sb.small[0][0] + small_base;
@@ -482,6 +485,7 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
         }
         div = xq_sum(dpart);
     }
+    mid(f4, div);
 
     // ------------------------------------------------------------------ reverse sweep
     f32x4 cot[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -783,7 +787,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     int phase = PH_F0, stage = 0;
     int nacc = 0, nrej = 0, status = 0, nrun = 0;
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
-    float sc[kCE];
+    float sc[kCE];   // scale of the initial-step heuristic (the solve's initial state)
+#pragma unroll
+    for (int c = 0; c < kCE; ++c) sc[c] = atol + fabsf(y0[c]) * rtol;
     Acc16<SPREAD> acc, gfirst, glast;   // acc: the attempt's weighted sums; gfirst / glast: unweighted sums of its first / seventh stage
     acc.zero();
     gfirst.zero();
@@ -809,9 +815,51 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
         // (zeroed) buffer before and after
         if (to_first) { gfirst.zero(); swap16(acc, gfirst); }
         if (to_last) { glast.zero(); swap16(acc, glast); }
+        // the controller's sums over (z, logp) need f and div only: the grid reduction is published from the middle of the
+        // evaluation and collected after the reverse sweep (see dopri5_bwd_split_kernel, cnf_split.hip); same sums, same bits
+        auto control_sums = [&](const float (&kc)[kCE], double (&S)[4]) {
+#pragma unroll
+            for (int c = 0; c < kCE; ++c) {
+                const bool cnt = c < 4 ? cz : cl;
+                if (phase == PH_F0) {
+                    const float u = y0[c] / sc[c], v = kc[c] / sc[c];
+                    if (cnt) {
+                        S[c < 4 ? 0 : 1] += (double)u * u;
+                        S[c < 4 ? 2 : 3] += (double)v * v;
+                    }
+                } else if (phase == PH_F1) {
+                    const float u = (kc[c] - sb.kst[0][c][lane]) / sc[c];
+                    if (cnt) S[c < 4 ? 0 : 1] += (double)u * u;
+                } else {
+                    float err = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) err += (dtf * kCErr[s]) * sb.kst[s][c][lane];
+                    err += (dtf * kCErr[6]) * kc[c];
+                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(yi[c]));   // yi: the candidate y1
+                    const float u = err / tol;
+                    if (cnt) {
+                        S[c < 4 ? 0 : 1] += (double)u * u;
+                        if (!isfinite(y0[c])) S[2] += 1.0;
+                    }
+                }
+            }
+            if (phase == PH_F1 && nll) S[2] = (cz ? (double)nll_part : 0.0) - (cl ? (double)y0[4] : 0.0);
+        };
+        bool early = false;
+        auto mid = [&](const f32x4& f_, float div_) {
+            if (a.adj_all || (phase == PH_STAGE && stage != 6)) return;
+            float kc[kCE];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kc[r] = sgn * fmaf(-res, z4[r], f_[r]);
+            kc[4] = -sgn * (div_ - res * (float)kD);
+            double S[4] = {0, 0, 0, 0};
+            control_sums(kc, S);
+            wg_reduce_publish<true>(gs, red, S, w, lane);
+            early = true;
+        };
         aug_eval16(net, sb, xc, w1img, w4img, w1Timg, w4Timg, lane, w, sgn * ti, z4, e4, az4, al, sgn * wst, with_theta, f4, div,
                    vz4, acc.dw(0), acc.dw(1), acc.thin(0), acc.thin(1), part,
-                   to_first ? i_first * kSm16 : (to_last ? i_last * kSm16 : 0));
+                   to_first ? i_first * kSm16 : (to_last ? i_last * kSm16 : 0), mid);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
             f4[r] = fmaf(-res, z4[r], f4[r]);
@@ -832,16 +880,15 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
             double S[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < kCA; ++c) sb.kst[0][c][lane] = k[c];
+            if (early) {
+                if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            } else {
+                float kc[kCE];
 #pragma unroll
-            for (int c = 0; c < kCE; ++c) {
-                sc[c] = atol + fabsf(y0[c]) * rtol;
-                const float u = y0[c] / sc[c], v = k[c] / sc[c];
-                if (c < 4 ? cz : cl) {
-                    S[c < 4 ? 0 : 1] += (double)u * u;
-                    S[c < 4 ? 2 : 3] += (double)v * v;
-                }
+                for (int c = 0; c < kCE; ++c) kc[c] = k[c];
+                control_sums(kc, S);
+                if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
-            if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
             d1z = (float)sqrt(S[2] / nz);
             d1l = (float)sqrt(S[3] / nl);
@@ -876,20 +923,22 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
         }
         if (phase == PH_F1) {
             double S[4] = {0, 0, 0, 0};
+            if (early) {
+                if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            } else {
+                float kc[kCE];
 #pragma unroll
-            for (int c = 0; c < kCE; ++c) {
-                const float u = (k[c] - sb.kst[0][c][lane]) / sc[c];
-                if (c < 4 ? cz : cl) S[c < 4 ? 0 : 1] += (double)u * u;
-            }
-            if (nll) S[2] = (cz ? (double)nll_part : 0.0) - (cl ? (double)y0[4] : 0.0);
-            if (a.adj_all && cz) {
+                for (int c = 0; c < kCE; ++c) kc[c] = k[c];
+                control_sums(kc, S);
+                if (a.adj_all && cz) {
 #pragma unroll
-                for (int c = 5; c < kCA; ++c) {
-                    const float u = (k[c] - sb.kst[0][c][lane]) / (atol + fabsf(y0[c]) * rtol);
-                    S[3] += (double)u * u;
+                    for (int c = 5; c < kCA; ++c) {
+                        const float u = (k[c] - sb.kst[0][c][lane]) / (atol + fabsf(y0[c]) * rtol);
+                        S[3] += (double)u * u;
+                    }
                 }
+                if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
-            if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * inv_rows);
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
             const float d2a = (float)sqrt(S[3] / nz) / h0;
@@ -904,29 +953,25 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
                 double S[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int c = 0; c < kCA; ++c) y1[c] = yi[c];
+                if (early) {
+                    if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                } else {
+                    float kc[kCE];
 #pragma unroll
-                for (int c = 0; c < kCE; ++c) {
-                    float err = 0.f;
+                    for (int c = 0; c < kCE; ++c) kc[c] = k[c];
+                    control_sums(kc, S);
+                    if (a.adj_all) {   // a_z under error control as well
 #pragma unroll
-                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * sb.kst[s][c][lane];
-                    const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c]));
-                    const float u = err / tol;
-                    if (c < 4 ? cz : cl) {
-                        S[c < 4 ? 0 : 1] += (double)u * u;
-                        if (!isfinite(y0[c])) S[2] += 1.0;
+                        for (int c = 5; c < kCA; ++c) {
+                            float err = 0.f;
+#pragma unroll
+                            for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * sb.kst[s][c][lane];
+                            const float u = err / (atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c])));
+                            if (cz) S[3] += (double)u * u;
+                        }
                     }
+                    if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 }
-                if (a.adj_all) {   // a_z under error control as well
-#pragma unroll
-                    for (int c = 5; c < kCA; ++c) {
-                        float err = 0.f;
-#pragma unroll
-                        for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * sb.kst[s][c][lane];
-                        const float u = err / (atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c])));
-                        if (cz) S[3] += (double)u * u;
-                    }
-                }
-                if (!wg_allreduce4<true>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
                 const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
                 const float ra = (float)(S[3] / nz);   // 0 unless CNF_FLAG_ADJ_CONTROL_ALL (a_logp's ratio is always 0)

@@ -426,6 +426,9 @@ def parse_args(argv=None):
     p.add_argument("--atol", type=float, default=1e-5)
     p.add_argument("--rtol", type=float, default=1e-5)
     p.add_argument("--step_size", type=float, default=None)
+    p.add_argument("--adjoint_error_control", type=str, default="state_only", choices=["state_only", "all"],
+                   help="which tensors of the adjoint state steer the backward solve: (z, logp) as the reference's length-2 "
+                        "tolerance lists do (default), or the per-row adjoints as well (CNF_FLAG_ADJ_CONTROL_ALL; not in the reference)")
     p.add_argument("--eval_size", type=int, default=100000)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--save", type=str, default="experiments/gu_ffjord")
@@ -460,9 +463,10 @@ def main(argv=None):
         logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of concatsquash CNF blocks of hidden "
                     "width 64 / 256 only)")
         args.fused = 0
-    if args.step_size:
-        for block in model.chain:
-            if isinstance(block, CNF):
+    for block in model.chain:
+        if isinstance(block, CNF):
+            block.adjoint_error_control = args.adjoint_error_control
+            if args.step_size:
                 block.solver_options["step_size"] = args.step_size
     logger.info("parameters: %d" % count_parameters(model))
     model.train()
