@@ -591,15 +591,44 @@ def measure_eval(ctx):
         ctx["barrier"]()
         sel = ctx["max_over_ranks"](time.perf_counter() - t0)
         smp_mean = smp.double().mean().item()
+    tfl = ll_evals * F_EVAL_D1 / eel / 1e12
     return {"value": round(rows / eel, 1), "unit": "samples/s", "rows": rows, "scaling": "strong",
             "mean_log_likelihood": round(mean_lp, 5), "rank0_mean_nfe": round(ll_evals / max(1, n_loc), 1),
             "rank0_max_nfe": work["nfe_max"],
-            "rank0_tflops": round(ll_evals * F_EVAL_D1 / eel / 1e12, 3),
+            "rank0_tflops": round(tfl, 3),
+            "roofline": eval_roofline(tfl),
             "sampling": {"value": round(args.eval_rows / sel, 1), "unit": "samples/s", "rows": args.eval_rows,
                          "rank0_sample_mean": round(smp_mean, 4)},
             "workload": "log-likelihood of %d synthetic points, then %d samples, under the trained gu_num=8 CNF (d=1 "
                         "checkpoint), tile-local dopri5 1e-5, batch-sharded, one all-reduce of 2 x f64"
                         % (rows, args.eval_rows)}
+
+
+def eval_roofline(tflops):
+    """The tile-local evaluation kernel against the two bounds that apply to it.  Its matrix work runs on the bf16 pipe
+    (three-piece operands), so the fp32 matrix peak is a yardstick for the fp32-equivalent FLOP rate, not the limit; the
+    limit is vector-instruction issue.  `valu_issue.busy_frac` = SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / waves per SIMD)
+    from this round's rocprofv3 --pmc pass over tools/time_eval.py (profiles/): not measurable in-process."""
+    import glob
+    out = {"bound": "mfma", "kernel": "dopri5_kernel<1,false,false,4,true>", "achieved": round(tflops, 3), "peak": PEAK_FP32_MATRIX_TFLOPS,
+           "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP32_MATRIX_TFLOPS, 4),
+           "peak_note": "dense fp32 matrix peak; FLOP counted as fp32 work (the kernel's hidden layers run on the bf16 pipe)",
+           "valu_issue": None}
+    path = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_eval_sq_pmc_summary.txt"))) or [""])[-1]
+    if os.path.exists(path):
+        tot = {}
+        with open(path) as fh:
+            for line in fh:
+                if "dopri5_kernel<1, false, false" in line and " total " in line:
+                    parts = line.split()
+                    name = [w for w in parts if w.startswith("SQ_")][0]
+                    tot[name] = float(parts[parts.index("total") + 1])
+        if "SQ_ACTIVE_INST_VALU" in tot and "SQ_WAVE_CYCLES" in tot:
+            waves_per_simd = 2   # amdgpu_waves_per_eu of the kernel (cnf_fwd.hip, kEvalB16Waves)
+            out["valu_issue"] = {"busy_frac": round(tot["SQ_ACTIVE_INST_VALU"] / (tot["SQ_WAVE_CYCLES"] / waves_per_simd), 3),
+                                 "valu_per_mfma": round(tot.get("SQ_INSTS_VALU", 0.0) / max(1.0, tot.get("SQ_INSTS_MFMA", 1.0)), 2),
+                                 "source": os.path.relpath(path, ROOT)}
+    return out
 
 
 def measure_cpu(ctx):
