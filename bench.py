@@ -257,7 +257,11 @@ def main():
     extras = set(e for e in args.extras.split(",") if e)
     ctx = dict(args=args, world=world, rank=rank, dev=dev, batches=batches, model=model, barrier=barrier, spread=spread,
                max_over_ranks=max_over_ranks, fused_run=fused_run)
-    if "pair" in extras:
+    if "pair" in extras and not spread:
+        # ranks share a GPU (gloo rehearsal on a box with fewer GPUs than ranks): two more trials per rank would need more
+        # co-resident workgroups than the device has compute units -- the solves' grid reductions would time out
+        out["two_trials_per_gpu"] = {"skipped": "ranks share a GPU in this run (BENCH_DIST_BACKEND rehearsal)"}
+    elif "pair" in extras:
         # first: whether two streams of one process overlap depends on how many streams / graphs the process has used
         # so far (ROCm multiplexes streams onto 4 hardware queues); after the measurements below they no longer do
         out["two_trials_per_gpu"] = measure_pair(ctx)
