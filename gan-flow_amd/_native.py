@@ -8,7 +8,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
-ACTIVATIONS = {"tanh": 0, "softplus": 1, "elu": 2}   # cnf_activation() of the library built for each (csrc/Makefile)
+ACTIVATIONS = {"tanh": 0, "softplus": 1, "elu": 2, "relu": 3}   # cnf_activation() of the library built for each (csrc/Makefile)
 
 
 class CnfError(RuntimeError):
@@ -56,7 +56,7 @@ EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval
 
 
 def library_path(act="tanh"):
-    """One shared object per ODEnet nonlinearity: libcnf_hip.so (tanh), libcnf_hip_softplus.so, libcnf_hip_elu.so."""
+    """One shared object per ODEnet nonlinearity: libcnf_hip.so (tanh), libcnf_hip_softplus.so, libcnf_hip_elu.so, libcnf_hip_relu.so."""
     if act not in ACTIVATIONS:
         raise CnfError("nonlinearity %r is not built into the HIP path (have: %s)" % (act, ", ".join(ACTIVATIONS)))
     # CNF_HIP_LIB: another build of the tanh library (kernel timing experiments, tools/build_variants.sh)

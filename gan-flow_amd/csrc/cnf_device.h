@@ -90,8 +90,12 @@ __device__ __forceinline__ float act_dd(float x, float dx) { return dx * (1.0f -
 __device__ __forceinline__ float act_f(float u) { return u > 0.0f ? u : expm1f(u); }
 __device__ __forceinline__ float act_d(float x) { return x > 0.0f ? 1.0f : x + 1.0f; }
 __device__ __forceinline__ float act_dd(float x, float dx) { return x > 0.0f ? 0.0f : dx; }
+#elif CNF_ACT == 3   // relu, nn.ReLU: x = max(u, 0); act' = 1 where the unit is on (x > 0: at u = 0 torch's derivative is 0 too); act'' = 0
+__device__ __forceinline__ float act_f(float u) { return fmaxf(u, 0.0f); }
+__device__ __forceinline__ float act_d(float x) { return x > 0.0f ? 1.0f : 0.0f; }
+__device__ __forceinline__ float act_dd(float, float) { return 0.0f; }
 #else
-#error "CNF_ACT: 0 = tanh, 1 = softplus, 2 = elu"
+#error "CNF_ACT: 0 = tanh, 1 = softplus, 2 = elu, 3 = relu"
 #endif
 
 // wave-private LDS hand-off between lanes of ONE wave: program order is enough for the hardware

@@ -415,7 +415,7 @@ def parse_args(argv=None):
     p.add_argument("--num_blocks", type=int, default=1)
     p.add_argument("--layer_type", type=str, default="concatsquash",
                    choices=["ignore", "concat", "concatcoord", "concat_v2", "squash", "concatsquash"])
-    p.add_argument("--nonlinearity", type=str, default="tanh", choices=["tanh", "softplus", "elu"])
+    p.add_argument("--nonlinearity", type=str, default="tanh", choices=["tanh", "softplus", "elu", "relu"])
     p.add_argument("--residual", type=eval, default=False, choices=[True, False])
     p.add_argument("--batch_norm", type=eval, default=False, choices=[True, False])
     p.add_argument("--bn_lag", type=float, default=0.0)

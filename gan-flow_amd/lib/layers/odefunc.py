@@ -22,15 +22,15 @@ def divergence_approx(f, y, e=None):
 
 
 # the nonlinearities a kernel library is built for (csrc/cnf_device.h CNF_ACT, one shared object each): the reference's
-# `--nonlinearity` choices tanh (its runs and checkpoints), softplus and elu; relu / swish / square / identity are not built
-NONLINEARITIES = {"tanh": nn.Tanh, "softplus": nn.Softplus, "elu": nn.ELU}
+# `--nonlinearity` choices tanh (its runs and checkpoints), softplus, elu and relu; swish / square / identity are not built
+NONLINEARITIES = {"tanh": nn.Tanh, "softplus": nn.Softplus, "elu": nn.ELU, "relu": nn.ReLU}
 
 
 class ODEnet(nn.Module):
     """dim -> hidden_dims -> dim stack of time-conditioned linear layers with tanh between (not after) them.
     layer_type: 'concatsquash' (the reference's runs and checkpoints) or one of its special cases 'ignore', 'concat',
     'concatcoord', 'concat_v2', 'squash' (diffeq_layers/basic.py); 'hyper' and 'blend' have time-dependent weight
-    matrices and are not built.  nonlinearity: 'tanh', 'softplus' or 'elu' (one kernel library each).
+    matrices and are not built.  nonlinearity: 'tanh', 'softplus', 'elu' or 'relu' (one kernel library each).
 
     hidden_dims: three hidden layers.  The kernels are built for widths 64 and 256; any other widths (equal or not, up
     to 256) are presented to them zero-padded to the next kernel width (kernel_hidden): a padded feature has zero

@@ -123,7 +123,7 @@ typedef struct CnfStats {
 
 /* The ODEnet nonlinearity this library was compiled for (ODEnet(nonlinearity=...), the reference's --nonlinearity):
  * 0 = tanh (libcnf_hip.so; the reference's runs and checkpoints), 1 = softplus (libcnf_hip_softplus.so), 2 = elu
- * (libcnf_hip_elu.so).  Every library exports this same interface; the caller binds the one that matches its net.    */
+ * (libcnf_hip_elu.so), 3 = relu (libcnf_hip_relu.so).  Every library exports this same interface; the caller binds the one that matches its net.    */
 int cnf_activation(void);
 
 /* Number of floats in `params` for this net; < 0 if the net is not supported. */

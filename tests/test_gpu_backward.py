@@ -641,7 +641,7 @@ def test_flow_with_batch_norm_layers_trains_and_inverts():
     assert rel_err(xb, x) < 1e-3 and dlb.abs().max().item() < 5e-3
 
 
-@pytest.mark.parametrize("act", ["softplus", "elu"])
+@pytest.mark.parametrize("act", ["softplus", "elu", "relu"])
 @pytest.mark.parametrize("dim,hidden,hutch,rows", [(2, 64, False, 512), (1, 64, False, 5000), (16, 64, True, 300), (2, 256, False, 200),
                                                    (2, (40, 64, 24), False, 100)])
 def test_other_nonlinearities(act, dim, hidden, hutch, rows):

@@ -310,7 +310,7 @@ def test_build_model_with_batch_norm_layers():
 
 
 def test_one_library_per_nonlinearity():
-    """libcnf_hip.so / libcnf_hip_softplus.so / libcnf_hip_elu.so export the same C ABI and say what they were built for."""
+    """libcnf_hip.so / libcnf_hip_softplus.so / libcnf_hip_elu.so / libcnf_hip_relu.so export the same C ABI and say what they were built for."""
     from gan_flow_amd import _native
     from gan_flow_amd.lib.layers.odefunc import ODEfunc, ODEnet
     for act, code in _native.ACTIVATIONS.items():
@@ -322,7 +322,7 @@ def test_one_library_per_nonlinearity():
     with pytest.raises(NotImplementedError):
         ODEnet((64, 64, 64), (2,), nonlinearity="swish")
     with pytest.raises(_native.CnfError):
-        _native.net_desc(2, 64, 3, False, act="relu")
+        _native.net_desc(2, 64, 3, False, act="square")
 
 
 def test_three_piece_bf16_split_keeps_every_bit():
