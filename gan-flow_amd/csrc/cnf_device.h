@@ -737,20 +737,22 @@ constexpr unsigned kSpinLimit = 1u << 24;
 
 // returns false on timeout (status set in red.status).  All threads of the workgroup must call it.
 // ALLQ: all four lane quarters of a wave carry contributions (cnf_split16.hip), not just quarter 0.
-template <bool ALLQ = false>
+template <bool ALLQ = false, bool PART = true>   // PART: see wg_reduce_publish
 __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], int w, int lane) {
 #ifdef CNF_PROF_SYNC
     const unsigned long long t_in = clock64();
     unsigned long long t_done = t_in;
 #endif
+    if constexpr (PART) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = ALLQ ? xq_sum_f64(row16_sum(v[i])) : row16_sum(v[i]);
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) red.part[w][i] = v[i];
     }
+    }
     __syncthreads();
-    if (w == 0) {
+    if (PART && w == 0) {
         double s = 0.0;
         if (lane < 4) s = red.part[0][lane] + red.part[1][lane] + red.part[2][lane] + red.part[3][lane];
 #ifdef CNF_PROF_SYNC
@@ -838,18 +840,22 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
 // workgroup's partials and stores its granules; wg_reduce_collect polls and totals.  Arithmetic and summation order are those
 // of wg_allreduce4 (bit-identical totals).  red.part must stay untouched in between, and no other reduction may run.
 // All threads of the workgroup call both.
-template <bool ALLQ = false>
+// PART = false: a wave beyond the kNW that carry rows (the theta waves of an eight-wave workgroup, cnf_split.hip): it
+// contributes nothing and polls nothing, but takes part in the barriers, keeps the epoch and reads the totals.
+template <bool ALLQ = false, bool PART = true>
 __device__ inline void wg_reduce_publish(GridSync& gs, RedLds& red, double (&v)[4], int w, int lane) {
+    if constexpr (PART) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = ALLQ ? xq_sum_f64(row16_sum(v[i])) : row16_sum(v[i]);
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) red.part[w][i] = v[i];
     }
+    }
     __syncthreads();
     if (gs.nwg > 1) {
         gs.epoch += 1;
-        if (w == 0 && lane < 4) {
+        if (PART && w == 0 && lane < 4) {
             const double s = red.part[0][lane] + red.part[1][lane] + red.part[2][lane] + red.part[3][lane];
             unsigned long long* bank = gs.gran + (size_t)(gs.epoch & 1u) * (size_t)(gs.nwg * 4);
             const unsigned long long pk = ((unsigned long long)gs.epoch << 32) | (unsigned long long)__float_as_uint((float)s);
@@ -857,8 +863,9 @@ __device__ inline void wg_reduce_publish(GridSync& gs, RedLds& red, double (&v)[
         }
     }
 }
+template <bool PART = true>
 __device__ inline bool wg_reduce_collect(GridSync& gs, RedLds& red, double (&v)[4], int w, int lane) {
-    if (w == 0) {
+    if (PART && w == 0) {
         double s = 0.0;
         if (lane < 4) s = red.part[0][lane] + red.part[1][lane] + red.part[2][lane] + red.part[3][lane];
         if (gs.nwg > 1) {

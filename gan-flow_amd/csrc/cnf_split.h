@@ -111,8 +111,9 @@ __device__ __forceinline__ void load_weights_b16_global(SplitWeightsB16& wb, con
 // W[16(2ks + h) + 4q + r][16 wave + j'] (the A operand of W^T . cotangent for the wave's own INPUT-feature tile, in the k
 // order of publish_b16).  48 KB.
 typedef uint32_t WimgT16[2][kNW][2][3][64][4];
-template <int D>
+template <int D, int NTH = kThreads>   // NTH: threads of the workgroup, kThreads or 2 * kThreads
 __device__ inline void stage_wimgT16(WimgT16& img, const float* __restrict__ p, int tid) {
+    constexpr int NK = 2 * kThreads / NTH;   // 512 (row-group, column-group) elements in all
     const ParamLayout L = make_layout(D, kH);
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
         // a thread takes FOUR consecutive rows i of a weight matrix (the k index) and four columns: 4 x 16-byte loads (all
@@ -120,16 +121,16 @@ __device__ inline void stage_wimgT16(WimgT16& img, const float* __restrict__ p, 
         // the image -- 24 eight-byte LDS stores per thread (16-bit scatter stores: 96).
         // W[i][c]: i = 16 (2 ks + h) + 4 q + r is the k index, c = 16 wv + j' the output
         uint2* img64 = reinterpret_cast<uint2*>(&img[0][0][0][0][0][0]);
-        f32x4 v[2][4];
+        f32x4 v[NK][4];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = tid + kThreads * k, c4 = e & 15, iq = (e >> 4) & 15, l = e >> 8;
+        for (int k = 0; k < NK; ++k) {
+            const int e = tid + NTH * k, c4 = e & 15, iq = (e >> 4) & 15, l = e >> 8;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[k][r] = *reinterpret_cast<const f32x4*>(&p[L.w(1 + l) + (4 * iq + r) * kH + 4 * c4]);
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = tid + kThreads * k, c4 = e & 15, iq = (e >> 4) & 15, l = e >> 8;
+        for (int k = 0; k < NK; ++k) {
+            const int e = tid + NTH * k, c4 = e & 15, iq = (e >> 4) & 15, l = e >> 8;
             const int T = iq >> 2, q = iq & 3, ks = T >> 1;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -148,7 +149,7 @@ __device__ inline void stage_wimgT16(WimgT16& img, const float* __restrict__ p, 
         }
         return;
     }
-    for (int idx = tid; idx < 2 * kNW * 2 * 64 * 4; idx += kThreads) {
+    for (int idx = tid; idx < 2 * kNW * 2 * 64 * 4; idx += NTH) {
         const int v = idx & 3, lane = (idx >> 2) & 63, ks = (idx >> 8) & 1, wv = (idx >> 9) & 3, l = idx >> 11;
         const int col = 16 * wv + (lane & 15);
         const int e0 = 2 * v, e1 = 2 * v + 1;

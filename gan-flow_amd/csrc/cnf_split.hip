@@ -463,6 +463,14 @@ struct alignas(16) SplitBwdLds : BwdWimgT<D, kBwdB16<D>>, BwdTransposes<D, kBwdB
     float wq[8];                          // quadrature weights of the current attempt
 };
 
+// two-workgroups-per-tile adjoint launches (d <= 2) run eight waves per workgroup, kThetaWavesNote; the switch exists
+// for A/B timing (tools/build_variants.sh nothetawaves "-DCNF_NO_THETA_WAVES")
+#ifdef CNF_NO_THETA_WAVES
+constexpr bool kThetaWaves = false;
+#else
+constexpr bool kThetaWaves = true;
+#endif
+
 // timing experiments only (tools/build_variants.sh): drop parts of the d/dtheta work to see what they cost
 #ifdef CNF_EXP_NO_SMALL
 constexpr bool kExpSmall = false;
@@ -476,13 +484,14 @@ constexpr bool kExpDw = true;
 #endif
 
 // the adjoint kernels' weights: fp32 images of W and W^T in LDS, or (kBwdB16) register pieces of W + an LDS image of W^T pieces
-template <int D>
+template <int D, int NTH = kThreads>   // NTH: threads of the workgroup (the first kNW waves hold the register pieces)
 __device__ __forceinline__ void stage_bwd_net(BwdNet<D>& net, SplitBwdLds<D>& sb, SplitWeightsB16& wb, const float* __restrict__ p, int tid) {
     if constexpr (kBwdB16<D>) {
-        stage_net_vectors<D>(net, p, tid);
-        stage_wimgT16<D>(sb.wimgT16, p, tid);
-        load_weights_b16_global<D>(wb, p, tid >> 6, tid & 63);
+        stage_net_vectors<D>(net, p, tid, NTH);
+        stage_wimgT16<D, NTH>(sb.wimgT16, p, tid);
+        if (NTH == kThreads || tid < kThreads) load_weights_b16_global<D>(wb, p, tid >> 6, tid & 63);
     } else {
+        static_assert(kBwdB16<D> || NTH == kThreads, "eight-wave workgroups: bf16 pipe only");
         stage_net(net, p, tid);
         stage_wimgT<D>(&sb.wimgT[0][0][0][0], p, tid);
     }
@@ -497,7 +506,11 @@ struct NoMid {
     template <class F>
     __device__ __forceinline__ void operator()(const F&, float) const {}
 };
-template <int D, bool HUTCH, class WS, int NL, class Mid>
+// ROLE (theta waves, kThetaWavesNote): 0 = this wave does everything (four-wave workgroups); 1 = state work and the
+// small-parameter sums, no outer products (a producer wave of an eight-wave workgroup); 2 = ONLY the outer products of
+// feature tile `wave`, read from the piece buffers the producers publish (a theta wave: it takes part in every barrier
+// of the evaluation and in mid(), and touches none of z, e, az, f, div, vz).
+template <int D, bool HUTCH, int ROLE = 0, class WS, int NL, class Mid>
 __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWeightsB16& wb, SplitBwdLds<D>& sb, WS& ws,
                                                BwdXchg<D>& xc, int lane,
                                                int wave, float t, const float (&z)[D], const float (&e)[D],
@@ -505,6 +518,8 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                                                float& div, float (&vz)[D], BigAccT<NL>& acc, BigAccT<NL>& alt, bool to_alt,
                                                int small_base, int part, Prof& pr, Mid&& mid) {
     constexpr bool B16 = kBwdB16<D>;
+    constexpr bool P = ROLE != 2, T = ROLE != 1;   // this wave does the state work / the outer products
+    static_assert(ROLE == 0 || B16, "separate theta waves read the bf16 piece buffers");
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     using SI = SmallIdxS<D>;
@@ -515,7 +530,7 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
     const int q = lane >> 4, j = lane & 15, qq = j & 3;
     const int fo = 16 * wave + 4 * q;
     const int pos = (j & 3) * 4 + (j >> 2);
-    gates_into(n, ws, lane, wave, t);
+    if constexpr (P) gates_into(n, ws, lane, wave, t);
     pr.mark(1);
     // after reduce8 lane j owns index r* = j & 3 and parameter kind j >> 2 (bias, hyper-bias, gate weight, gate bias):
     // factor = k0 * g + k1 * t + gg * (k2 * t + k3) as arithmetic on lane masks (nested selects compile to branches)
@@ -526,6 +541,7 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
     // ------------------------------------------------------------------ forward with saves (own tile)
     f32x4 xs[3], ub[3], U[2][NT], act[NS];
     f32x4 w1c[D];
+    if constexpr (P) {
 #pragma unroll
     for (int m = 0; m < D; ++m) w1c[m] = *reinterpret_cast<const f32x4*>(&n.w1[m][fo]);
     {
@@ -553,15 +569,16 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
             }
         }
     }
+    }
     pr.mark(2);
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
         f32x4 a4[NS];
         if constexpr (B16) {
-            publish_b16<NS>(xc.xa[l], act, wave, lane);
+            if constexpr (P) publish_b16<NS>(xc.xa[l], act, wave, lane);
             __syncthreads();
             pr.mark(3 + 3 * l);
-            hidden_b16<NS>(xc.xa[l], wb, l, lane, a4);
+            if constexpr (P) hidden_b16<NS>(xc.xa[l], wb, l, lane, a4);
             pr.mark(4 + 3 * l);
         } else {
 #pragma unroll
@@ -581,6 +598,7 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                     for (int s = 0; s < NS; ++s) a4[s] = mfma16(a[r], in[s][r], a4[s]);
             }
         }
+        if constexpr (P) {
         const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][0][fo]);
         const f32x4 c = *reinterpret_cast<const f32x4*>(&ws.gate[l + 1][1][fo]);
         const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[l + 1][0][fo]);
@@ -597,9 +615,11 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                 act[s][r] = dg * a4[s][r];
             }
         }
+        }
         pr.mark(5 + 3 * l);
     }
     f32x4 w4[D];
+    if constexpr (P) {
 #pragma unroll
     for (int m = 0; m < D; ++m) {
         w4[m] = *reinterpret_cast<const f32x4*>(&n.w4[m][fo]);
@@ -616,21 +636,26 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
             xc.part[wave][D + m][j] = pd;
         }
     }
+    }
     pr.mark(9);
     // The last layer's partial sums meet behind the SAME barrier as the reverse sweep's first exchange: nothing the sweep
     // needs up to there depends on f or div (its cotangents are -a_z and a_logp), so f, div and the last layer's vector
     // gradients -- the only consumers of the cross-wave sums -- are formed after that barrier (finish_forward below).
     float g4[D];
+    if constexpr (P) {
 #pragma unroll
     for (int m = 0; m < D; ++m) g4[m] = ws.gate4[0][m];
+    }
 
     // ------------------------------------------------------------------ reverse sweep (own tile)
     float lf[D];
+    if constexpr (P) {
 #pragma unroll
     for (int m = 0; m < D; ++m) lf[m] = -az[m];
+    }
     const float ld = al;
     f32x4 cot[NS];
-    {
+    if constexpr (P) {
         float ubar[D], Ubar[D];
 #pragma unroll
         for (int m = 0; m < D; ++m) {
@@ -665,6 +690,7 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
         }
     }
     auto finish_forward = [&]() {   // behind the first barrier of the sweep
+        if constexpr (P) {
         float u4[D], U4[D];
         div = 0.f;
 #pragma unroll
@@ -686,7 +712,8 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                 if (wave == 0 && lane < 4) lds_add(&small[SI::l4 + kH * D + qq * D + m], w * fac * val);
             }
         }
-        mid(f, div);
+        }
+        mid(f, div);   // every wave: the solve kernel's reduction has a workgroup barrier in it
     };
 
     pr.mark(12);
@@ -732,8 +759,10 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
 #pragma unroll
     for (int l = 1; l >= -1; --l) {
         const int L = l + 1;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(&ws.gate[L][0][fo]);
+        f32x4 g;
         float s1[4], s2[4];
+        if constexpr (P) {
+        g = *reinterpret_cast<const f32x4*>(&ws.gate[L][0][fo]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float x = xs[L][r];
@@ -762,10 +791,13 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
             s2[r] = fmaf(pre, ub[L][r], q2);
             cot[0][r] = g[r] * pre;
         }
-        if (l == 0 ? th_hi : th_lo) {
-            if (kExpDw && l < 1) issue_dw(l + 1);   // the previous layer's outer products, next to this vector work
         }
-        if ((L == 2 ? th_hi : th_lo) && kExpSmall) {
+        if constexpr (T) {
+            if (l == 0 ? th_hi : th_lo) {
+                if (kExpDw && l < 1) issue_dw(l + 1);   // the previous layer's outer products, next to this vector work
+            }
+        }
+        if constexpr (P) if ((L == 2 ? th_hi : th_lo) && kExpSmall) {
             // every lane ends up owning one (feature fo + r*, kind) entry of this layer's four vectors: no branch, no idle lane
             float st, gt;
             reduce8(s1, s2, b0, b1, st, gt);
@@ -779,7 +811,7 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
             const int lc = l < 0 ? 0 : l;
             const int buf = 1 - lc;   // layer 3 publishes through buffer 0, layer 2 through buffer 1
             if constexpr (B16) {
-                publish_b16<NS>(xc.xcot[lc], cot, wave, lane);
+                if constexpr (P) publish_b16<NS>(xc.xcot[lc], cot, wave, lane);
             } else {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
@@ -818,7 +850,7 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
             // cotangent of this layer's input, own input-feature tile: (W^T ubar)[16*wave ..]
             f32x4 o4[NS];
             if constexpr (B16) {
-                hidden_b16_lds<NS>(xc.xcot[lc], sb.wimgT16[lc][wave], lane, o4);
+                if constexpr (P) hidden_b16_lds<NS>(xc.xcot[lc], sb.wimgT16[lc][wave], lane, o4);
             } else {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) o4[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -834,10 +866,13 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                         for (int s = 0; s < NS; ++s) o4[s] = mfma16(a[r], in[s][r], o4[s]);
                 }
             }
+            if constexpr (P) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) cot[s] = o4[s];
+            }
             pr.mark(l == 1 ? 15 : 18);
         } else {
+            if constexpr (P) {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 float pz = 0.f;
@@ -861,10 +896,13 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                     if (kind < 2 && m + kind < D) lds_add(&small[(fo + qq) * D + m + kind], w * (kind == 0 ? ta : tb));
                 }
             }
+            }
             __syncthreads();
+            if constexpr (P) {
 #pragma unroll
             for (int m = 0; m < D; ++m)
                 vz[m] = sum4(sb.part2[0][m][j], sb.part2[1][m][j], sb.part2[2][m][j], sb.part2[3][m][j]);
+            }
             pr.mark(11);
         }
     }
@@ -872,32 +910,39 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
 
 // Two-workgroups-per-tile launches keep running totals over the accepted steps -- the matrix in 16 registers, the small
 // parameters in sb.small[3] -- and store their slab ONCE when the solve ends: no global read-modify-write between steps.
-template <int D>
+// MATS: this wave holds matrix accumulators (every wave of a four-wave workgroup; the theta waves of an eight-wave one).
+// NTH: threads of the workgroup; the small-parameter sums are spread over all of them.  w: the wave's feature tile.
+template <int D, bool MATS = true, int NTH = kThreads>
 __device__ inline void commit_total(SplitBwdLds<D>& sb, BigAccT<1>& tot, const BigAccT<1>& acc, const BigAccT<1>& gfirst,
                                     const BigAccT<1>& glast, int i_first, int i_last, float w_first, float w_last, int tid, int part) {
     const int i_lo = part == 1 ? SmallIdxS<D>::v3 : 0, i_hi = part == 2 ? SmallIdxS<D>::v3 : SmallIdxS<D>::count;
     __syncthreads();
-    for (int i = i_lo + tid; i < i_hi; i += kThreads)
+    for (int i = i_lo + tid; i < i_hi; i += NTH)
         sb.small[3][i] += fmaf(w_last, sb.small[i_last][i], fmaf(w_first, sb.small[i_first][i], sb.small[0][i]));
+    if constexpr (MATS) {
 #pragma unroll
     for (int Ti = 0; Ti < 4; ++Ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             tot.gw[0][Ti][r] += fmaf(w_last, glast.gw[0][Ti][r], fmaf(w_first, gfirst.gw[0][Ti][r], acc.gw[0][Ti][r]));
+    }
     __syncthreads();
 }
-template <int D>
-__device__ inline void store_total(const SplitBwdLds<D>& sb, const BigAccT<1>& tot, float* __restrict__ slab_wg, int tid, int part) {
+template <int D, bool MATS = true, int NTH = kThreads>
+__device__ inline void store_total(const SplitBwdLds<D>& sb, const BigAccT<1>& tot, float* __restrict__ slab_wg, int tid, int w,
+                                   int part) {
     const ParamLayout L = make_layout(D, kH);
-    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int lane = tid & 63, q = lane >> 4, j = lane & 15;
     const int i_lo = part == 1 ? SmallIdxS<D>::v3 : 0, i_hi = part == 2 ? SmallIdxS<D>::v3 : SmallIdxS<D>::count;
     __syncthreads();
-    for (int i = i_lo + tid; i < i_hi; i += kThreads) slab_wg[SmallIdxS<D>::canonical(i)] = sb.small[3][i];
+    for (int i = i_lo + tid; i < i_hi; i += NTH) slab_wg[SmallIdxS<D>::canonical(i)] = sb.small[3][i];
+    if constexpr (MATS) {
     const int l = 2 - part;   // part 1 keeps W3 (layer index 1 of the two hidden matrices), part 2 keeps W2
 #pragma unroll
     for (int Ti = 0; Ti < 4; ++Ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] = tot.gw[0][Ti][r];
+    }
 }
 
 template <int D>
@@ -1003,9 +1048,22 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
 
 // RUNTOT: the launch has two workgroups per tile (a.spread) and each keeps ONE matrix: accumulators of 16 registers, so
 // a fourth one -- the running total over accepted steps -- fits, and the slab is stored once at the end (commit_total).
-template <int D, bool HUTCH, bool RUNTOT>
-__global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a) {
+//
+// kThetaWavesNote -- TW: EIGHT waves per workgroup, two per SIMD.  Waves 0..3 ("producers") integrate the tile as before
+// but form no outer products; waves 4..7 ("theta waves") do nothing else: wave 4 + i reads the cotangent and layer-input
+// pieces the producers have published in LDS (they are the operands of the outer products as they lie there), forms the
+// 16 x 64 block of dW that producer i used to form, and keeps that block's four accumulators (attempt, two FSAL buffers,
+// running total) in ITS registers.  With one wave per SIMD nothing hides the producers' latencies (the vector ALU is
+// busy a third of the time); the theta wave's LDS reads, MFMAs and multiply-adds issue in those gaps.  Both kinds of
+// wave run the same controller on the same totals (every decision is a function of the grid-wide sums in red.tot and of
+// launch constants), so they take the same branches and meet at the same barriers; the body below is instantiated once
+// per role (ROLE of aug_eval_split) from ONE text, which is what keeps the barrier sequences equal.  Each role is
+// register-allocated on its own: 256 registers per wave.  The arithmetic of every sum is unchanged (bit-identical results).
+template <int D, bool HUTCH, bool RUNTOT, bool TW = false>
+__global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split_kernel(SolveArgs a) {
     static_assert(!RUNTOT || kFsalTheta<D>, "running totals are built for the FSAL kernels (d <= 2)");
+    static_assert(!TW || (RUNTOT && kBwdB16<D>), "theta waves: two-workgroups-per-tile launches on the bf16 pipe");
+    constexpr int NTH = TW ? 2 * kThreads : kThreads;
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int C = 2 * D + 1;
     constexpr int CE = D + 1;
@@ -1015,7 +1073,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     __shared__ SplitWaveLds<C> wl[kShareWaveLds<D> ? 1 : kNW];
     __shared__ BwdXchg<D> xc;
     __shared__ RedLds red;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15;
+    const int wv = TW ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);   // TW: a scalar, the roles branch on it
+    const int w = TW ? (wv & (kNW - 1)) : wv;                                    // the wave's feature tile
     if (tid == 0) red.status = 0;
     // kSpreadNote -- a.spread: TWO workgroups per 16-row tile (grid = 2 x tiles, for batches that would leave half the
     // compute units idle).  Both integrate the tile's state identically -- same arithmetic, same totals from the grid
@@ -1025,7 +1085,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     const int part = a.spread ? 1 + (int)(blockIdx.x & 1) : 0;
     const long row = (long)tile * kRows + j;
     const bool valid = row < a.rows;
-    const bool counted = valid && lane < 16 && w == 0 && part != 2;
+    const bool counted = valid && lane < 16 && wv == 0 && part != 2;
     const long rr = valid ? row : a.rows - 1;
     SplitWaveLds<C>& ws = wl[kShareWaveLds<D> ? 0 : w];
     float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;
@@ -1052,10 +1112,16 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     const int after_status = a.after ? a.after->status : 0;
     // staging comes AFTER the loads above were requested: the rows' round trip to memory overlaps it (dopri5_split_kernel)
     SplitWeightsB16 wb;
-    stage_bwd_net<D>(net, sb, wb, a.params, tid);
-    zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid);
-    for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += kThreads) (&sb.small[0][0])[i] = 0.f;
+    stage_bwd_net<D, NTH>(net, sb, wb, a.params, tid);
+    zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid, NTH);
+    for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += NTH) (&sb.small[0][0])[i] = 0.f;
     __syncthreads();
+
+    // everything from here on once per role (kThetaWavesNote): 0 = a wave of a four-wave workgroup, 1 = producer, 2 = theta wave
+    auto run = [&](auto role_c) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr bool P = ROLE != 2, T = ROLE != 1;
+    (void)T;
 #pragma unroll
     for (int c = 0; c < C; ++c) yi[c] = y0[c];
 
@@ -1071,8 +1137,10 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
     int nacc = 0, nrej = 0, status = 0, nrun = 0;
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[CE];   // scale of the initial-step heuristic (the solve's initial state)
+    if constexpr (P) {
 #pragma unroll
     for (int c = 0; c < CE; ++c) sc[c] = atol + fabsf(y0[c]) * rtol;
+    }
     constexpr bool FSAL = kFsalTheta<D>;
     BigAccT<NL> acc, gfirst, glast, total;   // acc: the attempt's weighted sums; gfirst / glast: see kFsalTheta; total: RUNTOT
     acc.zero();
@@ -1140,45 +1208,55 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         bool early = false;   // this evaluation's reduction is already under way (uniform)
         auto mid = [&](const float (&f_)[D], float div_) {
             if (a.adj_all || (phase == PH_STAGE && stage != 6)) return;
+            double S[4] = {0, 0, 0, 0};
+            if constexpr (P) {
             float kc[CE];
 #pragma unroll
             for (int m = 0; m < D; ++m) kc[m] = sgn * fmaf(-res, zz[m], f_[m]);
             kc[D] = -sgn * (div_ - res * (float)D);
-            double S[4] = {0, 0, 0, 0};
             control_sums(kc, S);
-            wg_reduce_publish(gs, red, S, w, lane);
+            }
+            wg_reduce_publish<false, P>(gs, red, S, w, lane);
             early = true;
         };
-        aug_eval_split<D, HUTCH>(net, wb, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc, glast,
-                                 to_alt, small, part, pr, mid);
+        aug_eval_split<D, HUTCH, ROLE>(net, wb, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc,
+                                       glast, to_alt, small, part, pr, mid);
+        if constexpr (P) {
         #pragma unroll
         for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
             f[m] = fmaf(-res, zz[m], f[m]);
             vz[m] = fmaf(res, az[m], vz[m]);
         }
         div -= res * (float)D;
+        }
         if (to_first) gfirst = glast;   // once per solve; the restart below clears glast
         ++nrun;
         pr.mark(20);
+        if constexpr (P) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             k[m] = sgn * f[m];
             k[D + 1 + m] = sgn * vz[m];
         }
         k[D] = -sgn * div;
+        }
 
         if (phase == PH_F0) {
             double S[4] = {0, 0, 0, 0};
+            if constexpr (P) {
 #pragma unroll
             for (int c = 0; c < C; ++c) ws.kst[0][c][j] = k[c];
+            }
             if (early) {
-                if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_reduce_collect<P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             } else {
+                if constexpr (P) {
                 float kc[CE];
 #pragma unroll
                 for (int c = 0; c < CE; ++c) kc[c] = k[c];
                 control_sums(kc, S);
-                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                }
+                if (!wg_allreduce4<false, P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
             const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
             d1z = (float)sqrt(S[2] / nz);
@@ -1186,8 +1264,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             float d0a = 0.f, d1a = 0.f, d0al = 0.f;
             if (a.adj_all) {   // CNF_FLAG_ADJ_CONTROL_ALL (cnf_device.h): a_z and a_logp take part in the heuristic
                 double S2[4] = {0, 0, 0, 0};
-                adj_all_f0_sums<D, C>(y0, k, al, rtol, atol, counted, S2);
-                if (!wg_allreduce4(gs, red, S2, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if constexpr (P) adj_all_f0_sums<D, C>(y0, k, al, rtol, atol, counted, S2);
+                if (!wg_allreduce4<false, P>(gs, red, S2, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 d0a = (float)sqrt(S2[0] / nz);
                 d1a = (float)sqrt(S2[1] / nz);
                 d0al = (float)sqrt(S2[2] / nl);
@@ -1195,8 +1273,10 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             }
             h0 = initial_h0(d0z, d0l, d1z, d1l, a.adj_all != 0, d0a, d1a, d0al);
             if (h0 < INFINITY) {
+                if constexpr (P) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) yi[c] = y0[c] + h0 * k[c];
+                }
                 ti = t0f + h0;
             }   // else (adj_all): the second evaluation runs at the initial state; initial_dt() ignores what it returns
             phase = PH_F1;
@@ -1205,8 +1285,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         if (phase == PH_F1) {
             double S[4] = {0, 0, 0, 0};
             if (early) {
-                if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_reduce_collect<P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             } else {
+                if constexpr (P) {
                 float kc[CE];
 #pragma unroll
                 for (int c = 0; c < CE; ++c) kc[c] = k[c];
@@ -1219,7 +1300,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                         S[3] += (double)u * u;
                     }
                 }
-                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                }
+                if (!wg_allreduce4<false, P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
             if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * inv_rows);
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
@@ -1227,18 +1309,23 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             dt = (double)initial_dt(h0, d1z, d1l, d2z, d2l, a.adj_all != 0, a.adj_all ? red.keep[0] : 0.f, d2a);
             restart = true;
         } else {
+            if constexpr (P) {
 #pragma unroll
             for (int c = 0; c < C; ++c) ws.kst[stage][c][j] = k[c];
+            }
             if (stage < 6) {
                 ++stage;
             } else {
                 double S[4] = {0, 0, 0, 0};
+                if constexpr (P) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) y1[c] = yi[c];
+                }
                 pr.mark(21);
                 if (early) {
-                    if (!wg_reduce_collect(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                    if (!wg_reduce_collect<P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 } else {
+                    if constexpr (P) {
                     float kc[CE];
 #pragma unroll
                     for (int c = 0; c < CE; ++c) kc[c] = k[c];
@@ -1254,7 +1341,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                             if (counted) S[3] += (double)u * u;
                         }
                     }
-                    if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                    }
+                    if (!wg_allreduce4<false, P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 }
                 pr.mark(22);
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
@@ -1263,15 +1351,19 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                 const bool accept = (rz <= 1.f) && (rl <= 1.f) && (ra <= 1.f);
                 if (accept) {
                     ++nacc;
-                    if constexpr (RUNTOT) commit_total<D>(sb, total, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], tid, part);
+                    if constexpr (RUNTOT) commit_total<D, T, NTH>(sb, total, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], tid, part);
                     else if constexpr (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], slab, tid, nacc == 1, part);
                     else commit_step_split<D>(sb, acc, slab, tid, nacc == 1, part);
                     if (!(tau_end > tau + dt)) break;
+                    if constexpr (P) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) y0[c] = y1[c];
+                    }
                     if (FSAL) {
+                        if constexpr (P) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) ws.kst[0][c][j] = k[c];   // the seventh stage is the next step's first
+                        }
                         gfirst = glast;
                         const int t_ = i_first;
                         i_first = i_last;
@@ -1297,7 +1389,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             acc.zero();
             if (FSAL) glast.zero();
             __syncthreads();   // every wave is past its last read of small of the previous attempt
-            for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) {
+            for (int i = tid; i < SmallIdxS<D>::padded; i += NTH) {
                 sb.small[0][i] = 0.f;
                 if (FSAL) sb.small[i_last][i] = 0.f;
             }
@@ -1329,6 +1421,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
             __syncthreads();
             pr.mark(25);
         }
+        if constexpr (P) {
         if (stage == 0) {
             ti = t0f;
 #pragma unroll
@@ -1336,11 +1429,12 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         } else {
             ti = t0f + stage_state(stage, dtf, y0, [&](int s, int c) { return ws.kst[s][c][j]; }, yi) * dtf;
         }
+        }
         pr.mark(26);
     }
 
     const unsigned taken = grid_ticket(gs, tid);   // all waves are past the last reduction's closing barrier
-    if (status == 0) {
+    if (P && status == 0) {
         const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
         const float x = (te - ta) / (tb - ta);
         const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
@@ -1361,7 +1455,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
         }
         if (counted) a.grad_logp0[row] = al;
     }
-    if constexpr (RUNTOT) store_total<D>(sb, total, slab, tid, part);
+    if constexpr (RUNTOT) store_total<D, T, NTH>(sb, total, slab, tid, w, part);
     grid_cleanup(gs, red, tid, taken);
     write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
 #ifdef CNF_PROF_CYCLES
@@ -1379,6 +1473,13 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split_kernel(SolveArgs a)
                pr.acc[24] / n, pr.acc[25] / n, pr.acc[26] / n, pr.acc[0] / n);
     }
 #endif
+    };   // run
+    if constexpr (!TW) {
+        run(std::integral_constant<int, 0>{});
+    } else {
+        if (wv < kNW) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+    }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------
@@ -1507,7 +1608,7 @@ static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
     hipError_t res = hipSuccess;
     if constexpr (kFsalTheta<D>) {
-        res = a.spread ? check_resident(dopri5_bwd_split_kernel<D, HUTCH, true>, kThreads, 2 * grid)
+        res = a.spread ? check_resident(dopri5_bwd_split_kernel<D, HUTCH, true, kThetaWaves>, kThetaWaves ? 2 * kThreads : kThreads, 2 * grid)
                        : check_resident(dopri5_bwd_split_kernel<D, HUTCH, false>, kThreads, grid);
     } else {
         res = check_resident(dopri5_bwd_split_kernel<D, HUTCH, false>, kThreads, a.spread ? 2 * grid : grid);
@@ -1515,7 +1616,8 @@ static hipError_t split_bwd_t(const SolveArgs& a, hipStream_t s) {
     if (res != hipSuccess) return res;
     dbg_timing_begin(s);
     if constexpr (kFsalTheta<D>) {
-        if (a.spread) hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH, true>), dim3(2 * grid), dim3(kThreads), 0, s, a);
+        if (a.spread) hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH, true, kThetaWaves>), dim3(2 * grid),
+                                         dim3(kThetaWaves ? 2 * kThreads : kThreads), 0, s, a);
         else hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
     } else {
         hipLaunchKernelGGL((dopri5_bwd_split_kernel<D, HUTCH, false>), dim3(a.spread ? 2 * grid : grid), dim3(kThreads), 0, s, a);
