@@ -386,7 +386,7 @@ def adjoint_roofline(model, x, spread, reps=20):
     st = _native.Stats(st)
     flops = rows * st.nfe * 3 * F_EVAL_D2
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "dopri5_bwd_split_kernel<2,false,%s>" % ("true" if spread else "false"),
+    return {"bound": "mfma", "kernel": "dopri5_bwd_split_kernel<2,false,%s>" % ("true,true" if spread else "false,false"),
             "achieved": round(achieved, 4), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5), "launch_ms": round(ms, 4), "call_ms": round(call_ms, 4),
             "nfe": st.nfe, "evals_run": st.evals_run, "us_per_evaluation": round(1e3 * ms / st.evals_run, 3),

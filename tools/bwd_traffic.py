@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-KERNEL = "dopri5_bwd_split_kernel<2, false, true>"
+KERNEL = "dopri5_bwd_split_kernel<2, false, true, true>"   # d = 2, exact trace, running totals, eight-wave workgroups
 
 
 def per_launch(path, counter):
