@@ -26,11 +26,6 @@ struct alignas(16) Wave16Lds {
     float kst[7][kC][64];   // Runge-Kutta slopes, one column per lane
 };
 
-struct alignas(16) Xchg16 {
-    float xb[2][2][4][64][4];   // hidden activations in C/D layout: [buffer][stream][feature tile][lane][r]
-    float part[kNW][2][64][4];  // layer-4 partial results of every wave: [wave][stream][lane][r]
-};
-
 // forward solve: hidden activations travel as bf16 pieces (cnf_split.h, publish_b16 / hidden_b16)
 struct alignas(16) Xchg16F {
     uint32_t xb16[2][2][3][2][64][4];   // [buffer][stream][piece][k-step][lane][tile & 1][2]
@@ -326,21 +321,23 @@ __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
 // =====================================================================================================================
 // adjoint (mathematics of aug_eval_split, cnf_split.hip; state layout as above)
 // =====================================================================================================================
-struct alignas(16) Net16Lds {   // NetLds<16> without the first / last layer weights (they live in registers here)
-    float wimg[2][16][64][4];
+// The adjoint's four hidden-layer products per evaluation (two forward, two transposed) and its outer products run on
+// the bf16 pipe with three-piece operands, as at d <= 2 (kBwdB16, cnf_split.hip): forward weight pieces in 48 registers per
+// lane, transposed pieces in a 48 KB LDS image, activations and cotangents published as pieces (cnf_split.h).
+struct alignas(16) Net16Lds {   // the vector parameters; the matrices live in registers (first / last layer, W pieces) and in Bwd16Lds
     float vec[3][4][kH];
     float vec4[4][16];
+};
+// the forward sweep's published activations (xa[l] = input of hidden layer l) stay until the end of the evaluation: they
+// are the B operands of that layer's outer products; the cotangents get buffers of their own
+struct alignas(16) Xchg16B {
+    uint32_t xa[2][2][3][2][64][4];     // [layer][stream][piece][k-step][lane][tile & 1][2]
+    uint32_t xcot[2][2][3][2][64][4];   // pre-activation cotangents of hidden layer lc
+    float part[kNW][2][64][4];          // layer-4 partial results of every wave: [wave][stream][lane][r]
 };
 
 __device__ inline void stage_net16(Net16Lds& n, const float* __restrict__ p, int tid) {
     const ParamLayout L = make_layout(kD, kH);
-    float* img = &n.wimg[0][0][0][0];
-    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += kThreads) {
-        const int r = idx & 3, lane = (idx >> 2) & 63, tt = (idx >> 8) & 15, l = idx >> 12;
-        const int row = 16 * (tt >> 2) + (lane & 15);
-        const int col = 16 * (tt & 3) + 4 * (lane >> 4) + r;
-        img[idx] = p[L.w(1 + l) + row * kH + col];
-    }
     for (int idx = tid; idx < 3 * kH; idx += kThreads) {
         const int l = idx / kH, i = idx % kH;
         n.vec[l][0][i] = p[L.b(l) + i];
@@ -362,9 +359,8 @@ constexpr int kSmV = 3 * 4 * kH;             // vector parameters of the three h
 constexpr int kSm16 = kSmV + 4 * kD;         // + those of the last layer: [kind][dimension]
 
 struct alignas(16) Bwd16Lds {
-    float wimgT[2][16][64][4];          // transposed images of the two 64 x 64 matrices
-    float trB[2][2][kH * kRows];        // transposed layer inputs, all 64 features: [buffer][stream][feature * 16 + pos(row)]
-    float trA[kNW][2][16 * kRows];      // per wave: transposed, weighted cotangents of its own 16 features
+    WimgT16 wimgT16;                    // transposed pieces of the two 64 x 64 matrices (stage_wimgT16, cnf_split.h)
+    float trA[kNW][2][16 * kRows];      // per wave: transposed, weighted first-layer cotangents of its own 16 features (dW1's A operand)
     float tX[kNW][2][16 * kRows];       // per wave: its tile of the last hidden layer's output, transposed (dW4's B operand)
     float tU[2][16 * kRows];            // weighted cotangents of the 16 outputs, transposed (dW4's A operand)
     float tZ[2][16 * kRows];            // [0] z, [1] e, transposed (dW1's B operands)
@@ -384,7 +380,7 @@ struct alignas(16) Bwd16Lds {
 // mid(f4, div): called by all threads when the forward half is done (the solve kernel starts its grid reduction there, as
 // dopri5_bwd_split_kernel does: cnf_split.hip)
 template <class Mid>
-__device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg16& xc, const f32x4& w1img, const f32x4& w4img,
+__device__ __forceinline__ void aug_eval16(const Net16Lds& n, const SplitWeightsB16& wb, Bwd16Lds& sb, Xchg16B& xc, const f32x4& w1img, const f32x4& w4img,
                                            const f32x4& w1Timg, const f32x4& w4Timg, int lane, int wave, float t,
                                            const f32x4& z4, const f32x4& e4, const f32x4& az4, float al, float w,
                                            bool with_theta, f32x4& f4, float& div, f32x4& vz4, f32x4 (&dw2)[4],
@@ -431,21 +427,10 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(&xc.xb[l][s][wave][lane][0]) = act[s];
+        publish_b16<2>(xc.xa[l], act, wave, lane);
         __syncthreads();
-        f32x4 a4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int Ti = 0; Ti < 4; ++Ti) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&n.wimg[l][wave * 4 + Ti][lane][0]);
-            f32x4 in[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[l][s][Ti][lane][0]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) a4[s] = mfma16(a[r], in[s][r], a4[s]);
-        }
+        f32x4 a4[2];
+        hidden_b16<2>(xc.xa[l], wb, l, lane, a4);
         const f32x4 g = *reinterpret_cast<const f32x4*>(&sb.gate[l + 1][0][fo]);
         const f32x4 c = *reinterpret_cast<const f32x4*>(&sb.gate[l + 1][1][fo]);
         const f32x4 b = *reinterpret_cast<const f32x4*>(&n.vec[l + 1][0][fo]);
@@ -533,21 +518,15 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
         }
     }
 
+    // unweighted outer products of this evaluation on the bf16 pipe (operands read transposed from the piece buffers,
+    // outer_b16 in cnf_split.h), then one fused multiply-add per accumulator register with the stage's quadrature weight
     auto issue_dw = [&](int lc) {
-        const int buf = 1 - lc;
+        f32x4 tmp[4];
+        outer_b16<2>(xc.xcot[lc], xc.xa[lc], wave, lane, tmp);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sb.trA[wave][s][j * kRows + 4 * q]);
-            f32x4 b4[4];
-#pragma unroll
-            for (int T = 0; T < 4; ++T) b4[T] = *reinterpret_cast<const f32x4*>(&sb.trB[buf][s][(16 * T + j) * kRows + 4 * q]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int Ti = 0; Ti < 4; ++Ti) {
-                    if (lc == 0) dw2[Ti] = mfma16(a4[ks], b4[Ti][ks], dw2[Ti]);
-                    else dw3[Ti] = mfma16(a4[ks], b4[Ti][ks], dw3[Ti]);
-                }
+        for (int Ti = 0; Ti < 4; ++Ti) {
+            if (lc == 0) dw2[Ti] += w * tmp[Ti];
+            else dw3[Ti] += w * tmp[Ti];
         }
     };
 
@@ -581,33 +560,10 @@ __device__ __forceinline__ void aug_eval16(const Net16Lds& n, Bwd16Lds& sb, Xchg
         }
         if (l >= 0) {
             const int lc = l < 0 ? 0 : l;
-            const int buf = 1 - lc;   // layer 3 publishes through buffer 0, layer 2 through buffer 1
-#pragma unroll
-            for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(&xc.xb[buf][s][wave][lane][0]) = cot[s];
-            if (lc == 1 ? th_hi : th_lo) {
-                const f32x4 gi = *reinterpret_cast<const f32x4*>(&sb.gate[L - 1][0][fo]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float xi = xs[L - 1][r];
-                    sb.trA[wave][0][(4 * q + r) * kRows + pos] = w * cot[0][r];
-                    sb.trA[wave][1][(4 * q + r) * kRows + pos] = w * cot[1][r];
-                    sb.trB[buf][0][(fo + r) * kRows + pos] = xi;
-                    sb.trB[buf][1][(fo + r) * kRows + pos] = act_d(xi) * gi[r] * U[L - 1][r];
-                }
-            }
+            publish_b16<2>(xc.xcot[lc], cot, wave, lane);   // the Wt product's B operand and the outer products' A operand
             __syncthreads();
-            f32x4 o4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int To = 0; To < 4; ++To) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&sb.wimgT[lc][wave * 4 + To][lane][0]);
-                f32x4 in[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) in[s] = *reinterpret_cast<const f32x4*>(&xc.xb[buf][s][To][lane][0]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) o4[s] = mfma16(a[r], in[s][r], o4[s]);
-            }
+            f32x4 o4[2];
+            hidden_b16_lds<2>(xc.xcot[lc], sb.wimgT16[lc][wave], lane, o4);
             cot[0] = o4[0];
             cot[1] = o4[1];
         } else {
@@ -722,13 +678,15 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ Net16Lds net;
     __shared__ Bwd16Lds sb;
-    __shared__ Xchg16 xc;
+    __shared__ Xchg16B xc;
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
     const int pos = (j & 3) * 4 + (j >> 2);
     if (tid == 0) red.status = 0;
     stage_net16(net, a.params, tid);
-    stage_wimgT<kD>(&sb.wimgT[0][0][0][0], a.params, tid);
+    stage_wimgT16<kD>(sb.wimgT16, a.params, tid);
+    SplitWeightsB16 wb;
+    load_weights_b16_global<kD>(wb, a.params, w, lane);
     for (int i = tid; i < 7 * kCA * 64; i += kThreads) (&sb.kst[0][0][0])[i] = 0.f;
     for (int i = tid; i < 3 * kSm16; i += kThreads) (&sb.small[0][0])[i] = 0.f;
     const ParamLayout L = make_layout(kD, kH);
@@ -857,7 +815,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
             wg_reduce_publish<true>(gs, red, S, w, lane);
             early = true;
         };
-        aug_eval16(net, sb, xc, w1img, w4img, w1Timg, w4Timg, lane, w, sgn * ti, z4, e4, az4, al, sgn * wst, with_theta, f4, div,
+        aug_eval16(net, wb, sb, xc, w1img, w4img, w1Timg, w4Timg, lane, w, sgn * ti, z4, e4, az4, al, sgn * wst, with_theta, f4, div,
                    vz4, acc.dw(0), acc.dw(1), acc.thin(0), acc.thin(1), part,
                    to_first ? i_first * kSm16 : (to_last ? i_last * kSm16 : 0), mid);
 #pragma unroll
