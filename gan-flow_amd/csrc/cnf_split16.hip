@@ -364,8 +364,9 @@ struct alignas(16) Bwd16Lds {
     float tX[kNW][2][16 * kRows];       // per wave: its tile of the last hidden layer's output, transposed (dW4's B operand)
     float tU[2][16 * kRows];            // weighted cotangents of the 16 outputs, transposed (dW4's A operand)
     float tZ[2][16 * kRows];            // [0] z, [1] e, transposed (dW1's B operands)
-    float small[3][kSm16];              // d/dtheta of the vector parameters: [0] weighted sum of the attempt, [1], [2] the
-                                        // unweighted sums of the first / seventh stage (FSAL, kFsalTheta in cnf_split.hip)
+    float small[4][kSm16];              // d/dtheta of the vector parameters: [0] weighted sum of the attempt, [1], [2] the
+                                        // unweighted sums of the first / seventh stage (FSAL, kFsalTheta in cnf_split.hip),
+                                        // [3] the running total over accepted steps (two-workgroups-per-tile launches)
     float wq[8];
     // one copy for the four waves (they hold identical values; readers and the next evaluation's writers are
     // separated by workgroup barriers), as are tU and tZ
@@ -671,6 +672,44 @@ __device__ inline void commit16(Bwd16Lds& sb, const Acc16<HALF>& A, const Acc16<
     __syncthreads();
 }
 
+// Two-workgroups-per-tile launches keep RUNNING TOTALS over the accepted steps (a fourth half set of registers, a fourth
+// LDS row) and store their half slab once, when the solve ends: no global read-modify-write between steps, as at d <= 2
+// (commit_total / store_total, cnf_split.hip).  The totals add up in the order the read-modify-writes did: same bits.
+__device__ inline void commit16_total(Bwd16Lds& sb, Acc16<true>& T, const Acc16<true>& A, const Acc16<true>& F, const Acc16<true>& G,
+                                      int i_first, int i_last, float w_first, float w_last, int tid, int part) {
+    const int i_lo = part == 1 ? 8 * kH : 0, i_hi = part == 2 ? 8 * kH : kSm16;   // layer-1/2 vectors | layer-3/4 vectors
+    __syncthreads();
+    for (int i = i_lo + tid; i < i_hi; i += kThreads)
+        sb.small[3][i] += fmaf(w_last, sb.small[i_last][i], fmaf(w_first, sb.small[i_first][i], sb.small[0][i]));
+#pragma unroll
+    for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T.m[0][Ti][r] += fmaf(w_last, G.m[0][Ti][r], fmaf(w_first, F.m[0][Ti][r], A.m[0][Ti][r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T.g[0][r] += fmaf(w_last, G.g[0][r], fmaf(w_first, F.g[0][r], A.g[0][r]));
+    __syncthreads();
+}
+__device__ inline void store16_total(const Bwd16Lds& sb, const Acc16<true>& T, float* __restrict__ slab_wg, int tid, int part) {
+    const ParamLayout L = make_layout(kD, kH);
+    const int lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int i_lo = part == 1 ? 8 * kH : 0, i_hi = part == 2 ? 8 * kH : kSm16;
+    __syncthreads();
+    for (int i = i_lo + tid; i < i_hi; i += kThreads) {
+        const int canon = i < kSmV ? L.b(i / (4 * kH)) + i % (4 * kH) : L.b(3) + (i - kSmV);
+        slab_wg[canon] = sb.small[3][i];
+    }
+    const int l = 2 - part;   // part 1 keeps W3 and W4, part 2 keeps W2 and W1
+#pragma unroll
+    for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] = T.m[0][Ti][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (part == 2) slab_wg[L.w(0) + (16 * w + 4 * q + r) * kD + j] = T.g[0][r];
+        else slab_wg[L.w(3) + (4 * q + r) * kH + 16 * w + j] = T.g[0][r];
+    }
+}
+
 // SPREAD: launched with two workgroups per tile (a.spread); half accumulators and FSAL for the theta quadrature (six
 // evaluations per attempt).  Otherwise one workgroup per tile keeps all sums and re-evaluates the first stage (seven).
 template <bool SPREAD>
@@ -688,7 +727,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     SplitWeightsB16 wb;
     load_weights_b16_global<kD>(wb, a.params, w, lane);
     for (int i = tid; i < 7 * kCA * 64; i += kThreads) (&sb.kst[0][0][0])[i] = 0.f;
-    for (int i = tid; i < 3 * kSm16; i += kThreads) (&sb.small[0][0])[i] = 0.f;
+    for (int i = tid; i < 4 * kSm16; i += kThreads) (&sb.small[0][0])[i] = 0.f;
     const ParamLayout L = make_layout(kD, kH);
     const f32x4 w1img = *reinterpret_cast<const f32x4*>(a.params + L.w(0) + (16 * w + j) * kD + 4 * q);
     const f32x4 w4img = *reinterpret_cast<const f32x4*>(a.params + L.w(3) + j * kH + 16 * w + 4 * q);
@@ -752,6 +791,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     acc.zero();
     gfirst.zero();
     glast.zero();
+    Acc16<true> total;             // SPREAD: the running total over accepted steps
+    total.zero();
     int i_first = 1, i_last = 2;   // which of sb.small[1], sb.small[2] holds the first / seventh stage's sums
 
     if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
@@ -936,7 +977,8 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
                 const bool accept = (rz <= 1.f) && (rl <= 1.f) && (ra <= 1.f);
                 if (accept) {
                     ++nacc;
-                    commit16(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid, nacc == 1, part);
+                    if constexpr (SPREAD) commit16_total(sb, total, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], tid, part);
+                    else commit16(sb, acc, gfirst, glast, i_first, i_last, sb.wq[0], sb.wq[6], slab, tid, nacc == 1, part);
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
                     for (int c = 0; c < kCA; ++c) y0[c] = y1[c];
@@ -1028,6 +1070,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
         if (cz) *reinterpret_cast<f32x4*>(a.grad_x + row * kD + 4 * q) = o;
         if (cl) a.grad_logp0[row] = al;
     }
+    if constexpr (SPREAD) store16_total(sb, total, slab, tid, part);
     grid_cleanup(gs, red, tid);
     write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
 }
