@@ -616,6 +616,17 @@ __device__ __forceinline__ float stage_state(int stage, float dtf, const float (
     }
 }
 
+// the time node of a stage, as stage_state returns it
+__device__ __forceinline__ float stage_node(int stage) {
+    switch (stage) {
+        case 1: return (float)(1.0 / 5);
+        case 2: return (float)(3.0 / 10);
+        case 3: return (float)(4.0 / 5);
+        case 4: return (float)(8.0 / 9);
+        default: return 1.f;
+    }
+}
+
 // stage_coeffs multiplies the slopes of stages that have not been evaluated yet by a zero weight, so those slots must
 // hold finite numbers from the start: LDS keeps whatever the previous kernel on the CU left there, and 0 * NaN = NaN.
 // Call before the kernel's first workgroup barrier; `n_ws` = number of per-wave blocks in `wl`.

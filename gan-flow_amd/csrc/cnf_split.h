@@ -15,6 +15,7 @@ __device__ __forceinline__ float row16_allsum_s(float v) {
 // NL = 2: both hidden matrices; NL = 1: the one matrix a workgroup of a two-workgroups-per-tile launch keeps (slot 0)
 template <int NL>
 struct BigAccT {
+    static constexpr int kNL = NL;
     f32x4 gw[NL][4];   // [layer][Tin]: lane (q, j') reg r = dW[16*wave+4q+r][16Tin+j']
     __device__ __forceinline__ void zero() {
 #pragma unroll

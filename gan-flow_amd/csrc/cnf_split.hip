@@ -454,13 +454,40 @@ struct BwdTransposes {
 };
 template <int D>
 struct BwdTransposes<D, true> {};              // kBwdB16: operands are read transposed from the piece buffers (outer_b16)
-template <int D>
-struct alignas(16) SplitBwdLds : BwdWimgT<D, kBwdB16<D>>, BwdTransposes<D, kBwdB16<D>> {
+template <int D, bool TW>
+struct BwdSmallLds {
     float small[kFsalTheta<D> ? 4 : 1][SmallIdxS<D>::padded];   // d/dtheta of the small parameters (waves own disjoint
                                           // features): [0] the step's weighted sum, [1], [2] the FSAL buffers, [3] the
                                           // running total over accepted steps (two-workgroups-per-tile launches)
+};
+// Eight-wave workgroups (kThetaWavesNote): the small-parameter sums live in the theta waves' REGISTERS (after reduce8 a lane
+// owns one entry per reduction: SmallRegs); the producers hand over what they used to reduce themselves -- eight floats
+// per lane and reduction -- through these buffers.  Which reduction uses which buffer, and why a reader is always
+// separated from the next writer by a workgroup barrier: kSmallBufNote in aug_eval_split.
+template <int D>
+struct BwdSmallLds<D, true> {
+    f32x4 sbuf[3][kNW][2][64];            // [buffer][producer wave][a | b][lane]
+    float l4pub[2][D][kRows];             // last layer's vectors: per-row operands of the two row sums (producer wave 0)
+};
+template <int D, bool TW = false>
+struct alignas(16) SplitBwdLds : BwdWimgT<D, kBwdB16<D>>, BwdTransposes<D, kBwdB16<D>>, BwdSmallLds<D, TW> {
     float part2[kNW][D][kRows];           // vjp_z partial sums of every wave
     float wq[8];                          // quadrature weights of the current attempt
+};
+// a theta wave's share of the small-parameter sums, one lane = one entry each (lane (q, j) of the wave for feature tile
+// w: feature fo + qq = 16 w + 4 q + (j & 3), kind = j >> 2 of bias | hyper-bias | gate weight | gate bias):
+//   e[0]  hidden layer vectors: layer 3 (part 1) or layer 2 (part 2), entry (kind, feature)
+//   e[1]  layer 1 vectors (part 2), entry (kind, feature)
+//   e[2]  W4[kind][feature] (part 1) or W1[feature][kind] (part 2), lanes with kind < D
+//   e[3 + m]  last layer's vector qq, output m (part 1, tile 0, lanes 0..3)
+template <int D>
+struct ThetaAccT : BigAccT<1> {
+    float e[3 + D];
+    __device__ __forceinline__ void zero() {
+        BigAccT<1>::zero();
+#pragma unroll
+        for (int i = 0; i < 3 + D; ++i) e[i] = 0.f;
+    }
 };
 
 // two-workgroups-per-tile adjoint launches (d <= 2) run eight waves per workgroup, kThetaWavesNote; the switch exists
@@ -484,8 +511,8 @@ constexpr bool kExpDw = true;
 #endif
 
 // the adjoint kernels' weights: fp32 images of W and W^T in LDS, or (kBwdB16) register pieces of W + an LDS image of W^T pieces
-template <int D, int NTH = kThreads>   // NTH: threads of the workgroup (the first kNW waves hold the register pieces)
-__device__ __forceinline__ void stage_bwd_net(BwdNet<D>& net, SplitBwdLds<D>& sb, SplitWeightsB16& wb, const float* __restrict__ p, int tid) {
+template <int D, int NTH = kThreads, class SB>   // NTH: threads of the workgroup (the first kNW waves hold the register pieces)
+__device__ __forceinline__ void stage_bwd_net(BwdNet<D>& net, SB& sb, SplitWeightsB16& wb, const float* __restrict__ p, int tid) {
     if constexpr (kBwdB16<D>) {
         stage_net_vectors<D>(net, p, tid, NTH);
         stage_wimgT16<D, NTH>(sb.wimgT16, p, tid);
@@ -510,15 +537,27 @@ struct NoMid {
 // small-parameter sums, no outer products (a producer wave of an eight-wave workgroup); 2 = ONLY the outer products of
 // feature tile `wave`, read from the piece buffers the producers publish (a theta wave: it takes part in every barrier
 // of the evaluation and in mid(), and touches none of z, e, az, f, div, vz).
-template <int D, bool HUTCH, int ROLE = 0, class WS, int NL, class Mid>
-__device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWeightsB16& wb, SplitBwdLds<D>& sb, WS& ws,
+//
+// kSmallBufNote -- ROLE 1 / 2: the small-parameter sums.  Where a four-wave workgroup runs reduce8 and adds the result to
+// its LDS sums, a producer stores the reduction's eight per-lane inputs (sb.sbuf) and the theta wave of the same feature
+// tile reduces them and adds the result -- same factors, same order of additions -- to its registers (ThetaAccT::e).
+//   part 1 (upper half):  W4 -> buffer 0 and layer 3 -> buffer 1, written before the sweep's first barrier, read behind it;
+//                         the last layer's vectors -> l4pub, written behind the first barrier, read behind the second.
+//   part 2 (lower half):  layer 2 -> buffer 0, written before the sweep's second barrier, read behind it; layer 1 ->
+//                         buffer 1 and W1 -> buffer 2, written before the evaluation's last barrier, read behind it.
+// A buffer's next writer is the same point of the NEXT evaluation, at least four barriers after its reader.  The gates
+// the factors need are read before the evaluation's last barrier (the producers overwrite them right after it).
+template <int D, bool HUTCH, int ROLE = 0, class WS, class SB, class Acc, class Mid>
+__device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWeightsB16& wb, SB& sb, WS& ws,
                                                BwdXchg<D>& xc, int lane,
                                                int wave, float t, const float (&z)[D], const float (&e)[D],
                                                const float (&az)[D], float al, float w, bool with_theta, float (&f)[D],
-                                               float& div, float (&vz)[D], BigAccT<NL>& acc, BigAccT<NL>& alt, bool to_alt,
+                                               float& div, float (&vz)[D], Acc& acc, Acc& alt, bool to_alt,
                                                int small_base, int part, Prof& pr, Mid&& mid) {
+    constexpr int NL = Acc::kNL;
     constexpr bool B16 = kBwdB16<D>;
     constexpr bool P = ROLE != 2, T = ROLE != 1;   // this wave does the state work / the outer products
+    static_assert(ROLE == 0 || D <= 2, "one reduce8 per weight block");
     static_assert(ROLE == 0 || B16, "separate theta waves read the bf16 piece buffers");
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
@@ -526,7 +565,8 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
     // part (uniform over the workgroup): which d/dtheta sums this workgroup keeps.  0 = all; 1 = the upper half
     // (W3, layer-3 vectors, W4, layer-4 vectors); 2 = the lower half (W1, layer-1/2 vectors, W2).  See kSpreadNote.
     const bool th_hi = with_theta && part != 2, th_lo = with_theta && part != 1;
-    float* const small = &sb.small[0][0] + small_base;   // an LDS address the compiler can see (no flat atomics)
+    float* small = nullptr;
+    if constexpr (ROLE == 0) small = &sb.small[0][0] + small_base;   // an LDS address the compiler can see (no flat atomics)
     const int q = lane >> 4, j = lane & 15, qq = j & 3;
     const int fo = 16 * wave + 4 * q;
     const int pos = (j & 3) * 4 + (j >> 2);
@@ -537,6 +577,28 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
     const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0;
     const int kind = j >> 2;
     const float km0 = kind == 0 ? 1.f : 0.f, km1t = kind == 1 ? t : 0.f, km23 = kind == 2 ? t : (kind == 3 ? 1.f : 0.f);
+    // ROLE 1: hand a reduction's inputs to the theta wave; ROLE 2: take them, reduce (kSmallBufNote)
+    auto put8 = [&](int buf, const float (&va)[4], const float (&vb)[4]) {
+        if constexpr (ROLE == 1) {
+            sb.sbuf[buf][wave][0][lane] = f32x4{va[0], va[1], va[2], va[3]};
+            sb.sbuf[buf][wave][1][lane] = f32x4{vb[0], vb[1], vb[2], vb[3]};
+        }
+    };
+    auto get8 = [&](int buf, float& ta, float& tb) {
+        if constexpr (ROLE == 2) {
+            const f32x4 A = sb.sbuf[buf][wave][0][lane], B = sb.sbuf[buf][wave][1][lane];
+            const float va[4] = {A[0], A[1], A[2], A[3]}, vb[4] = {B[0], B[1], B[2], B[3]};
+            reduce8(va, vb, b0, b1, ta, tb);
+        }
+    };
+    // the hidden layers' vector sums from the reduced (st, gt) and the lane's gate value gs
+    auto vec_term = [&](float st, float gt, float gs) {
+        const float gg = gs * (1.0f - gs);
+        const float fac = fmaf(gg, km23, fmaf(km0, gs, km1t));
+        return w * fac * (kind < 2 ? st : gt);
+    };
+    constexpr int kBufL0 = 1, kBufW1 = 2;
+    float gs_l1 = 0.f;   // ROLE 2, part 2: the lane's layer-1 gate, read before the evaluation's last barrier
 
     // ------------------------------------------------------------------ forward with saves (own tile)
     f32x4 xs[3], ub[3], U[2][NT], act[NS];
@@ -684,8 +746,12 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                     va[r] = ubar[m] * act[0][r] + Ubar[m] * act[HUTCH ? 1 : 1 + m][r];
                     vb[r] = m + 1 < D ? ubar[m + 1 < D ? m + 1 : m] * act[0][r] + Ubar[m + 1 < D ? m + 1 : m] * act[HUTCH ? 1 : 1 + (m + 1 < D ? m + 1 : m)][r] : 0.f;
                 }
-                reduce8(va, vb, b0, b1, ta, tb);
-                if (kind < 2 && m + kind < D) lds_add(&small[SI::l4 + (m + kind) * kH + fo + qq], w * (kind == 0 ? ta : tb));
+                if constexpr (ROLE == 1) {
+                    put8(0, va, vb);
+                } else {
+                    reduce8(va, vb, b0, b1, ta, tb);
+                    if (kind < 2 && m + kind < D) lds_add(&small[SI::l4 + (m + kind) * kH + fo + qq], w * (kind == 0 ? ta : tb));
+                }
             }
         }
     }
@@ -704,12 +770,20 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
         if (th_hi) {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
-                const float s4 = row16_allsum_s(lf[m]);
-                const float gb = row16_allsum_s(lf[m] * (u4[m] + n.vec4[0][m]) + ld * (HUTCH ? e[m] : 1.0f) * U4[m]);
-                const float gg = g4[m] * (1.0f - g4[m]);
-                const float val = qq < 2 ? s4 : gb;
-                const float fac = qq == 0 ? g4[m] : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
-                if (wave == 0 && lane < 4) lds_add(&small[SI::l4 + kH * D + qq * D + m], w * fac * val);
+                const float pa = lf[m], pb = lf[m] * (u4[m] + n.vec4[0][m]) + ld * (HUTCH ? e[m] : 1.0f) * U4[m];
+                if constexpr (ROLE == 1) {
+                    if (wave == 0 && q == 0) {
+                        sb.l4pub[0][m][j] = pa;
+                        sb.l4pub[1][m][j] = pb;
+                    }
+                } else {
+                    const float s4 = row16_allsum_s(pa);
+                    const float gb = row16_allsum_s(pb);
+                    const float gg = g4[m] * (1.0f - g4[m]);
+                    const float val = qq < 2 ? s4 : gb;
+                    const float fac = qq == 0 ? g4[m] : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
+                    if (wave == 0 && lane < 4) lds_add(&small[SI::l4 + kH * D + qq * D + m], w * fac * val);
+                }
             }
         }
         }
@@ -797,14 +871,43 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                 if (kExpDw && l < 1) issue_dw(l + 1);   // the previous layer's outer products, next to this vector work
             }
         }
+        if constexpr (ROLE == 2) if (kExpSmall) {   // kSmallBufNote
+            Acc& dst = to_alt ? alt : acc;
+            float ta = 0.f, tb = 0.f;
+            if (l == 0 && th_hi) {          // behind the sweep's first barrier: W4 and layer 3
+                get8(0, ta, tb);
+                dst.e[2] += w * (kind == 0 ? ta : tb);   // every lane: entries of lanes with kind >= D are never stored
+                get8(1, ta, tb);
+                dst.e[0] += vec_term(ta, tb, ws.gate[2][0][fo + qq]);
+            }
+            if (l == -1 && th_hi) {         // behind the second: the last layer's vectors
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    const float s4 = row16_allsum_s(sb.l4pub[0][m][j]);
+                    const float gb = row16_allsum_s(sb.l4pub[1][m][j]);
+                    const float g4m = ws.gate4[0][m];
+                    const float gg = g4m * (1.0f - g4m);
+                    const float val = qq < 2 ? s4 : gb;
+                    const float fac = qq == 0 ? g4m : (qq == 1 ? t : (qq == 2 ? t * gg : gg));
+                    if (wave == 0 && lane < 4) dst.e[3 + m] += w * fac * val;
+                }
+            }
+            if (l == -1 && th_lo) {         // behind the second: layer 2; layer 1's gate for later
+                get8(0, ta, tb);
+                dst.e[0] += vec_term(ta, tb, ws.gate[1][0][fo + qq]);
+                gs_l1 = ws.gate[0][0][fo + qq];
+            }
+        }
         if constexpr (P) if ((L == 2 ? th_hi : th_lo) && kExpSmall) {
             // every lane ends up owning one (feature fo + r*, kind) entry of this layer's four vectors: no branch, no idle lane
-            float st, gt;
-            reduce8(s1, s2, b0, b1, st, gt);
-            const float gs = b1 ? (b0 ? g[3] : g[2]) : (b0 ? g[1] : g[0]);
-            const float gg = gs * (1.0f - gs);
-            const float fac = fmaf(gg, km23, fmaf(km0, gs, km1t));
-            lds_add(&small[SI::vec(L) + kind * kH + fo + qq], w * fac * (kind < 2 ? st : gt));
+            if constexpr (ROLE == 1) {
+                put8(L == 2 ? 1 : (L == 1 ? 0 : kBufL0), s1, s2);
+            } else {
+                float st, gt;
+                reduce8(s1, s2, b0, b1, st, gt);
+                const float gs = b1 ? (b0 ? g[3] : g[2]) : (b0 ? g[1] : g[0]);
+                lds_add(&small[SI::vec(L) + kind * kH + fo + qq], vec_term(st, gt, gs));
+            }
         }
         pr.mark(l == 1 ? 13 : (l == 0 ? 16 : 19));
         if (l >= 0) {
@@ -891,13 +994,32 @@ __device__ __forceinline__ void aug_eval_split(const BwdNet<D>& n, const SplitWe
                     for (int r = 0; r < 4; ++r) {
                         va[r] = fmaf(cot[0][r], z[m], HUTCH ? cot[1][r] * e[m] : cot[1 + (HUTCH ? 0 : m)][r]);
                         vb[r] = m + 1 < D ? fmaf(cot[0][r], z[m1], HUTCH ? cot[1][r] * e[m1] : cot[1 + (HUTCH ? 0 : m1)][r]) : 0.f;
+#ifndef CNF_EXP_TW_PACKED_W1
+                        // kPackedW1Note: each value on its own through an opaque statement, so that the compiler cannot form
+                        // these multiply-adds as PACKED fp32 instructions (v_pk_fma_f32 with op_sel).  In an eight-wave
+                        // workgroup the low halves of exactly these packed results came out wrong in the last quarter of
+                        // the wave, now and then; scalar multiply-adds of the same operands do not.
+                        if constexpr (ROLE == 1) asm volatile("" : "+v"(va[r]), "+v"(vb[r]));
+#endif
                     }
-                    reduce8(va, vb, b0, b1, ta, tb);
-                    if (kind < 2 && m + kind < D) lds_add(&small[(fo + qq) * D + m + kind], w * (kind == 0 ? ta : tb));
+                    if constexpr (ROLE == 1) {
+                        put8(kBufW1, va, vb);
+                    } else {
+                        reduce8(va, vb, b0, b1, ta, tb);
+                        if (kind < 2 && m + kind < D) lds_add(&small[(fo + qq) * D + m + kind], w * (kind == 0 ? ta : tb));
+                    }
                 }
             }
             }
             __syncthreads();
+            if constexpr (ROLE == 2) if (th_lo && kExpSmall) {   // behind the evaluation's last barrier: layer 1 and W1
+                Acc& dst = to_alt ? alt : acc;
+                float ta = 0.f, tb = 0.f;
+                get8(kBufL0, ta, tb);
+                dst.e[1] += vec_term(ta, tb, gs_l1);
+                get8(kBufW1, ta, tb);
+                dst.e[2] += w * (kind == 0 ? ta : tb);   // every lane: entries of lanes with kind >= D are never stored
+            }
             if constexpr (P) {
 #pragma unroll
             for (int m = 0; m < D; ++m)
@@ -942,6 +1064,44 @@ __device__ inline void store_total(const SplitBwdLds<D>& sb, const BigAccT<1>& t
     for (int Ti = 0; Ti < 4; ++Ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] = tot.gw[0][Ti][r];
+    }
+}
+
+// eight-wave workgroups: a theta wave's own registers, matrices and small parameters alike (the arithmetic of commit_total)
+template <int D>
+__device__ __forceinline__ void commit_total_regs(ThetaAccT<D>& tot, const ThetaAccT<D>& acc, const ThetaAccT<D>& gfirst,
+                                                  const ThetaAccT<D>& glast, float w_first, float w_last) {
+#pragma unroll
+    for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            tot.gw[0][Ti][r] += fmaf(w_last, glast.gw[0][Ti][r], fmaf(w_first, gfirst.gw[0][Ti][r], acc.gw[0][Ti][r]));
+#pragma unroll
+    for (int i = 0; i < 3 + D; ++i) tot.e[i] += fmaf(w_last, glast.e[i], fmaf(w_first, gfirst.e[i], acc.e[i]));
+}
+// the theta wave of feature tile w stores what it owns (ThetaAccT): its 16 x 64 block of the part's matrix and one entry
+// per lane and small-parameter block
+template <int D>
+__device__ inline void store_total_regs(const ThetaAccT<D>& tot, float* __restrict__ slab_wg, int lane, int w, int part) {
+    using SI = SmallIdxS<D>;
+    const ParamLayout L = make_layout(D, kH);
+    const int q = lane >> 4, j = lane & 15, qq = j & 3, kind = j >> 2, fo = 16 * w + 4 * q;
+    const int l = 2 - part;   // part 1 keeps W3 (layer index 1 of the two hidden matrices), part 2 keeps W2
+#pragma unroll
+    for (int Ti = 0; Ti < 4; ++Ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab_wg[L.w(1 + l) + (16 * w + 4 * q + r) * kH + 16 * Ti + j] = tot.gw[0][Ti][r];
+    if (part == 1) {
+        slab_wg[SI::canonical(SI::vec(2) + kind * kH + fo + qq)] = tot.e[0];
+        if (kind < 2 && kind < D) slab_wg[SI::canonical(SI::l4 + kind * kH + fo + qq)] = tot.e[2];
+        if (w == 0 && lane < 4) {
+#pragma unroll
+            for (int m = 0; m < D; ++m) slab_wg[SI::canonical(SI::l4 + kH * D + qq * D + m)] = tot.e[3 + m];
+        }
+    } else {
+        slab_wg[SI::canonical(SI::vec(1) + kind * kH + fo + qq)] = tot.e[0];
+        slab_wg[SI::canonical(SI::vec(0) + kind * kH + fo + qq)] = tot.e[1];
+        if (kind < 2 && kind < D) slab_wg[SI::canonical((fo + qq) * D + kind)] = tot.e[2];
     }
 }
 
@@ -1068,9 +1228,13 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     constexpr int C = 2 * D + 1;
     constexpr int CE = D + 1;
     constexpr int NL = RUNTOT ? 1 : 2;
+    // TW: ONE copy of the gates and of the Runge-Kutta slopes for the four producers, as at d = 16 (kShareWaveLds): they
+    // hold identical values, a producer reads only the gates it wrote itself, and every reader of a slope is separated from
+    // the next evaluation's writers by a workgroup barrier.  The 12 KB pay for the hand-over buffers (BwdSmallLds).
+    constexpr bool SHARE = kShareWaveLds<D> || TW;
     __shared__ BwdNet<D> net;
-    __shared__ SplitBwdLds<D> sb;
-    __shared__ SplitWaveLds<C> wl[kShareWaveLds<D> ? 1 : kNW];
+    __shared__ SplitBwdLds<D, TW> sb;
+    __shared__ SplitWaveLds<C> wl[SHARE ? 1 : kNW];
     __shared__ BwdXchg<D> xc;
     __shared__ RedLds red;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15;
@@ -1087,7 +1251,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     const bool valid = row < a.rows;
     const bool counted = valid && lane < 16 && wv == 0 && part != 2;
     const long rr = valid ? row : a.rows - 1;
-    SplitWaveLds<C>& ws = wl[kShareWaveLds<D> ? 0 : w];
+    SplitWaveLds<C>& ws = wl[SHARE ? 0 : w];
     float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;
 
     GridSync gs{a.gran, (int)gridDim.x, 0u};
@@ -1113,8 +1277,9 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     // staging comes AFTER the loads above were requested: the rows' round trip to memory overlaps it (dopri5_split_kernel)
     SplitWeightsB16 wb;
     stage_bwd_net<D, NTH>(net, sb, wb, a.params, tid);
-    zero_slopes(wl, kShareWaveLds<D> ? 1 : kNW, tid, NTH);
-    for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += NTH) (&sb.small[0][0])[i] = 0.f;
+    zero_slopes(wl, SHARE ? 1 : kNW, tid, NTH);
+    if constexpr (!TW)
+        for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += NTH) (&sb.small[0][0])[i] = 0.f;
     __syncthreads();
 
     // everything from here on once per role (kThetaWavesNote): 0 = a wave of a four-wave workgroup, 1 = producer, 2 = theta wave
@@ -1142,7 +1307,9 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     for (int c = 0; c < CE; ++c) sc[c] = atol + fabsf(y0[c]) * rtol;
     }
     constexpr bool FSAL = kFsalTheta<D>;
-    BigAccT<NL> acc, gfirst, glast, total;   // acc: the attempt's weighted sums; gfirst / glast: see kFsalTheta; total: RUNTOT
+    // acc: the attempt's weighted sums; gfirst / glast: see kFsalTheta; total: RUNTOT.  TW: the small parameters' too.
+    using AccT = typename std::conditional<TW, ThetaAccT<D>, BigAccT<NL>>::type;
+    AccT acc, gfirst, glast, total;
     acc.zero();
     gfirst.zero();
     glast.zero();
@@ -1351,7 +1518,11 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                 const bool accept = (rz <= 1.f) && (rl <= 1.f) && (ra <= 1.f);
                 if (accept) {
                     ++nacc;
-                    if constexpr (RUNTOT) commit_total<D, T, NTH>(sb, total, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], tid, part);
+                    if constexpr (TW) {
+                        if constexpr (T) {
+                            commit_total_regs<D>(total, acc, gfirst, glast, wq[0], wq[6]);
+                        }
+                    } else if constexpr (RUNTOT) commit_total<D>(sb, total, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], tid, part);
                     else if constexpr (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], slab, tid, nacc == 1, part);
                     else commit_step_split<D>(sb, acc, slab, tid, nacc == 1, part);
                     if (!(tau_end > tau + dt)) break;
@@ -1388,10 +1559,12 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
             phase = PH_STAGE;
             acc.zero();
             if (FSAL) glast.zero();
+            if constexpr (!TW) {
             __syncthreads();   // every wave is past its last read of small of the previous attempt
-            for (int i = tid; i < SmallIdxS<D>::padded; i += NTH) {
+            for (int i = tid; i < SmallIdxS<D>::padded; i += kThreads) {
                 sb.small[0][i] = 0.f;
                 if (FSAL) sb.small[i_last][i] = 0.f;
+            }
             }
             // quadrature weights of the attempt: dt b_s, or on the step that passes the end time the dense-output weights
             // (tableau entries as literals; every lane computes all seven: no table loads, no LDS hand-off)
@@ -1418,7 +1591,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                     }
                 }
             }
-            __syncthreads();
+            if constexpr (!TW) __syncthreads();
             pr.mark(25);
         }
         if constexpr (P) {
@@ -1429,6 +1602,8 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
         } else {
             ti = t0f + stage_state(stage, dtf, y0, [&](int s, int c) { return ws.kst[s][c][j]; }, yi) * dtf;
         }
+        } else {
+            ti = t0f + stage_node(stage) * dtf;   // a theta wave needs the evaluation's time for the gate vectors' factors
         }
         pr.mark(26);
     }
@@ -1455,7 +1630,11 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
         }
         if (counted) a.grad_logp0[row] = al;
     }
-    if constexpr (RUNTOT) store_total<D, T, NTH>(sb, total, slab, tid, w, part);
+    if constexpr (TW) {
+        if constexpr (T) {
+            store_total_regs<D>(total, slab, lane, w, part);
+        }
+    } else if constexpr (RUNTOT) store_total<D>(sb, total, slab, tid, w, part);
     grid_cleanup(gs, red, tid, taken);
     write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
 #ifdef CNF_PROF_CYCLES

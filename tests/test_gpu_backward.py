@@ -535,6 +535,40 @@ def test_spread_adjoint_equals_plain_adjoint(dim, hutch, rows):
     assert outs[0][2].abs().max().item() > 0
 
 
+@pytest.mark.parametrize("dim,hutch", [(2, False), (1, False), (2, True)])
+def test_spread_slabs_equal_plain_slabs_per_tile(dim, hutch):
+    """The finest form of the comparison above: every entry of every workgroup's gradient slab.  A two-workgroups-per-tile
+    launch leaves, per tile, the lower half of the parameters in the odd workgroup's slab and the upper half in the even
+    one's; each owned entry must carry the bits of the one-workgroup-per-tile launch's slab of that tile.  (A sum over 128
+    tiles can hide a wrong contribution of one tile behind rounding; this cannot.  It is the check that found the packed-fp32
+    fault described in DESIGN.md section 4, kPackedW1Note in cnf_split.hip.)"""
+    nat = _native()
+    rows, H, gran = 2048, 64, 16448      # gran: bytes of reduction granules in front of the slabs (kGranBytes, cnf_api.hip)
+    g = torch.Generator().manual_seed(31)
+    m = oracle_random_model(dim, seed=9, divergence_fn="approximate" if hutch else "brute_force", scale=2.0)
+    net = nat.net_desc(dim, H, 3, hutch)
+    params = _flat(m).to(DEV)
+    P = params.numel()
+    x = torch.randn(rows, dim, generator=g).to(DEV)
+    e = torch.randn(rows, dim, generator=g).to(DEV) if hutch else None
+    z1, l1, _ = nat.solve_fwd(net, params, x, None, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5), e)
+    gz1, gl1 = z1 / rows, torch.full((rows, 1), 1.0 / rows, device=DEV)
+    tiles = rows // 16
+    w3 = dim * H + 4 * H + H * H + 4 * H          # first parameter of the upper half (W3)
+    slabs = {}
+    for flags, name, n in ((0, "plain", tiles), (nat.FLAG_SPREAD, "spread", 2 * tiles)):
+        ws = torch.full((gran + 4 * P * 2 * tiles + 4096,), 0x7F, dtype=torch.uint8, device=DEV)
+        st = nat.solve_bwd(net, params, z1, l1, gz1, gl1, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5, flags=flags), e, workspace=ws)[3]
+        torch.cuda.synchronize()
+        nat.Stats(st).raise_for_status()
+        slabs[name] = ws[gran:gran + 4 * P * n].view(torch.float32).view(n, P).cpu()
+    plain, spread = slabs["plain"], slabs["spread"]
+    lower, upper = spread[1::2], spread[0::2]
+    assert plain.abs().max().item() > 0
+    assert torch.equal(lower[:, :w3].view(torch.int32), plain[:, :w3].view(torch.int32))
+    assert torch.equal(upper[:, w3:].view(torch.int32), plain[:, w3:].view(torch.int32))
+
+
 @pytest.mark.parametrize("hidden", [(32, 32, 32), (48, 64, 16), (100, 100, 100), (7, 130, 64)])
 def test_other_hidden_widths_run_zero_padded(hidden):
     """Hidden widths other than 64 / 256 (ODEnet.kernel_hidden): the kernels see the net zero-padded to the next built

@@ -7,6 +7,8 @@ cd "$(dirname "$0")/../gan-flow_amd/csrc"
 mkdir -p ../variants
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off"
 SRC=${SRC:-cnf_split}
+# the files the Makefile compiles without packed-fp32 instructions (NOPK_FLAGS there)
+case $SRC in cnf_fwd|cnf_wide_bwd) FLAGS="$FLAGS -Xclang -target-feature -Xclang -packed-fp32-ops";; esac
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   /opt/rocm/bin/hipcc $FLAGS $defs -c $SRC.hip -o ../variants/${SRC}_$name.o
