@@ -498,6 +498,13 @@ constexpr bool kThetaWaves = false;
 constexpr bool kThetaWaves = true;
 #endif
 
+// kRematLaneNote (dopri5_bwd_split_kernel): which copies of the lane index pass through an opaque statement once per
+// loop iteration -- 1: the producers' evaluation, 2: the theta waves' evaluation, 4: the grid reductions (both roles)
+#ifndef CNF_REMAT_LANE
+#define CNF_REMAT_LANE 6
+#endif
+constexpr int kRematLane = CNF_REMAT_LANE;
+
 // timing experiments only (tools/build_variants.sh): drop parts of the d/dtheta work to see what they cost
 #ifdef CNF_EXP_NO_SMALL
 constexpr bool kExpSmall = false;
@@ -1323,6 +1330,17 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     for (; status == 0;) {
         float zz[D], az[D], f[D], vz[D], div, k[C];
         bool restart = false;
+        // kRematLaneNote -- eight-wave workgroups run at 256 registers per wave, and the compiler hoists everything that
+        // is a function of the lane index alone out of this loop: LDS addresses, lane masks, the 64-bit granule offsets of
+        // the grid reductions -- one or two instructions each to recompute, but spilled to scratch once hoisted (38 dwords
+        // per lane, re-read every evaluation, all of it written back to HBM when the kernel ends: 19.9 of the launch's
+        // 29.8 MB of traffic).  Passing the lane index through an opaque statement once per iteration makes the values
+        // derived from THAT copy loop-variant, so they are recomputed where they are used: the grid reductions' copy in
+        // both roles, the evaluation's copy in the theta waves (their vector ALU is mostly idle; on the producers' chain
+        // the recomputation costs what the reloads did -- CNF_REMAT_LANE bit 1, measured neutral to slightly slower).
+        // 152 -> 56 bytes of scratch per lane, 6.14 -> 5.91 us per evaluation on the stiff field; same arithmetic, same bits.
+        int lane_r = lane;   // the grid reductions' copy of the lane index
+        if constexpr (TW && (kRematLane & 4) != 0) asm volatile("" : "+v"(lane_r));
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             zz[m] = yi[m];
@@ -1383,10 +1401,12 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
             kc[D] = -sgn * (div_ - res * (float)D);
             control_sums(kc, S);
             }
-            wg_reduce_publish<false, P>(gs, red, S, w, lane);
+            wg_reduce_publish<false, P>(gs, red, S, w, lane_r);
             early = true;
         };
-        aug_eval_split<D, HUTCH, ROLE>(net, wb, sb, ws, xc, lane, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc,
+        int lane_e = lane;   // the evaluation's copy (kRematLaneNote)
+        if constexpr (TW && (kRematLane & ROLE) != 0) asm volatile("" : "+v"(lane_e));
+        aug_eval_split<D, HUTCH, ROLE>(net, wb, sb, ws, xc, lane_e, w, sgn * ti, zz, ee, az, al, sgn * wst, with_theta, f, div, vz, acc,
                                        glast, to_alt, small, part, pr, mid);
         if constexpr (P) {
         #pragma unroll
@@ -1415,7 +1435,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
             for (int c = 0; c < C; ++c) ws.kst[0][c][j] = k[c];
             }
             if (early) {
-                if (!wg_reduce_collect<P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_reduce_collect<P>(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             } else {
                 if constexpr (P) {
                 float kc[CE];
@@ -1423,7 +1443,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                 for (int c = 0; c < CE; ++c) kc[c] = k[c];
                 control_sums(kc, S);
                 }
-                if (!wg_allreduce4<false, P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_allreduce4<false, P>(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
             const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
             d1z = (float)sqrt(S[2] / nz);
@@ -1432,7 +1452,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
             if (a.adj_all) {   // CNF_FLAG_ADJ_CONTROL_ALL (cnf_device.h): a_z and a_logp take part in the heuristic
                 double S2[4] = {0, 0, 0, 0};
                 if constexpr (P) adj_all_f0_sums<D, C>(y0, k, al, rtol, atol, counted, S2);
-                if (!wg_allreduce4<false, P>(gs, red, S2, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_allreduce4<false, P>(gs, red, S2, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 d0a = (float)sqrt(S2[0] / nz);
                 d1a = (float)sqrt(S2[1] / nz);
                 d0al = (float)sqrt(S2[2] / nl);
@@ -1452,7 +1472,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
         if (phase == PH_F1) {
             double S[4] = {0, 0, 0, 0};
             if (early) {
-                if (!wg_reduce_collect<P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_reduce_collect<P>(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             } else {
                 if constexpr (P) {
                 float kc[CE];
@@ -1468,7 +1488,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                     }
                 }
                 }
-                if (!wg_allreduce4<false, P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_allreduce4<false, P>(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
             if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * inv_rows);
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
@@ -1490,7 +1510,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                 }
                 pr.mark(21);
                 if (early) {
-                    if (!wg_reduce_collect<P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                    if (!wg_reduce_collect<P>(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 } else {
                     if constexpr (P) {
                     float kc[CE];
@@ -1509,7 +1529,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                         }
                     }
                     }
-                    if (!wg_allreduce4<false, P>(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                    if (!wg_allreduce4<false, P>(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 }
                 pr.mark(22);
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
