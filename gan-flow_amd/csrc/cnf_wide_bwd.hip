@@ -29,6 +29,10 @@ struct WideSmallIdx {   // parameters other than the two 256x256 matrices, canon
 };
 
 constexpr int kWideBig = 2 * kWT * kWT * 64 * 4;   // floats of the two matrices' sums, [layer][To][Ti][lane][r]
+#ifndef CNF_WIDE_REMAT_LANE
+#define CNF_WIDE_REMAT_LANE 5
+#endif
+constexpr int kWideRematLane = CNF_WIDE_REMAT_LANE;   // wide_bwd_kernel: 1 = the evaluation's, 4 = the grid reductions' copy of the lane index
 constexpr int kWideSlots = 8;                      // 0..6: stage slots, 7: running total of the accepted steps
 constexpr int kWideTotal = 7;
 
@@ -608,7 +612,12 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
             slot_i = stage == 6 ? i_last : stage;
             with_theta = stage == 6 || wq[stage] != 0.f;
         }
-        aug_eval_wide<D, HUTCH>(net, ws, xc, part2, a.params, wt, lane, w, sgn * ti, zz, ee, az, al, sgn, with_theta, f, div, vz,
+        // kRematLaneNote (cnf_split.hip): values that are functions of the lane index alone are recomputed per iteration
+        // instead of being hoisted out of the loop and spilled (this kernel runs at 512 registers per wave)
+        int lane_e = lane, lane_r = lane;
+        if constexpr ((kWideRematLane & 1) != 0) asm volatile("" : "+v"(lane_e));
+        if constexpr ((kWideRematLane & 4) != 0) asm volatile("" : "+v"(lane_r));
+        aug_eval_wide<D, HUTCH>(net, ws, xc, part2, a.params, wt, lane_e, w, sgn * ti, zz, ee, az, al, sgn, with_theta, f, div, vz,
                                 region + (size_t)slot_i * kWideSlotF<D>, part);
         #pragma unroll
         for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
             }
 #pragma unroll
             for (int c = CE; c < C; ++c) ws.kst[0][c][j] = k[c];
-            if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            if (!wg_allreduce4(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
             d1z = (float)sqrt(S[2] / nz);
             d1l = (float)sqrt(S[3] / nl);
@@ -646,7 +655,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
             if (a.adj_all) {   // CNF_FLAG_ADJ_CONTROL_ALL (cnf_device.h): a_z and a_logp take part in the heuristic
                 double S2[4] = {0, 0, 0, 0};
                 adj_all_f0_sums<D, C>(y0, k, al, rtol, atol, counted, S2);
-                if (!wg_allreduce4(gs, red, S2, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_allreduce4(gs, red, S2, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 d0a = (float)sqrt(S2[0] / nz);
                 d1a = (float)sqrt(S2[1] / nz);
                 d0al = (float)sqrt(S2[2] / nl);
@@ -676,7 +685,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
                     S[3] += (double)u * u;
                 }
             }
-            if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+            if (!wg_allreduce4(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
             const float d2a = (float)sqrt(S[3] / nz) / h0;
             dt = (double)initial_dt(h0, d1z, d1l, d2z, d2l, a.adj_all != 0, a.adj_all ? red.keep[0] : 0.f, d2a);
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
                         if (counted) S[3] += (double)u * u;
                     }
                 }
-                if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                if (!wg_allreduce4(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
                 const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
                 const float ra = (float)(S[3] / nz);   // 0 unless CNF_FLAG_ADJ_CONTROL_ALL (a_logp's ratio is always 0)
