@@ -13,6 +13,7 @@ namespace cnf {
 hipError_t launch_eval_aug(int D, bool hutch, const SolveArgs& a, float t, const float* z, const float* a_z,
                            const float* a_logp, float* f_out, float* nd_out, float* vjp_z_out, hipStream_t s);
 hipError_t launch_solve_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
+hipError_t launch_fixed_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 // feature-split (one tile per workgroup) variants, cnf_split.hip
 hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
@@ -66,6 +67,7 @@ int fail(const char* fmt, ...) {
     return 1;
 }
 
+constexpr int64_t kFixedBwdMaxRows = 65536;   // fixed-grid adjoint: one gradient slab (37 KB) per 64 rows in the workspace
 constexpr size_t kGranBytes = 2 * (size_t)cnf::kMaxWG * 4 * sizeof(unsigned long long) + 64;  // 16 KiB of granules + the ticket word
 
 constexpr int kWideH = 256;   // cnf_wide.hip
@@ -418,7 +420,25 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
     if (train && (is_wide(net) || !use_split(net, rows)))
         return fail("%s: built for hidden width 64 and at most %d rows (got hidden %d, %ld rows); use cnf_nll_loss, "
                     "cnf_solve_bwd and cnf_adam_step", who, cnf::kRows * cnf::kMaxWG, net->hidden, (long)rows);
-    if (opts->solver != CNF_SOLVER_DOPRI5) return fail("%s: the adjoint pass is built for dopri5 only", who);
+    const bool fixed = opts->solver != CNF_SOLVER_DOPRI5;   // euler / midpoint / rk4: the adjoint runs on the same fixed grid, backwards
+    if (fixed) {
+        if (train) return fail("%s: built for dopri5; fixed-grid training goes through cnf_solve_bwd and cnf_adam_step", who);
+        if (is_wide(net) || net->dim > 2)
+            return fail("%s: the fixed-grid adjoint is built for hidden width 64 and dim <= 2 (got hidden %d, dim %d)", who,
+                        net->hidden, net->dim);
+        if (rows > kFixedBwdMaxRows)
+            return fail("%s: the fixed-grid adjoint supports at most %ld rows per call (got %ld)", who, (long)kFixedBwdMaxRows, (long)rows);
+        if (opts->step_size > 0.f) {
+            // the grid of the backward solve starts at t1: torchdiffeq's grid constructor on the negated time axis
+            const float sgn = t0 >= t1 ? 1.f : -1.f;
+            const float tau0 = sgn * t1, tau1 = sgn * t0;
+            const float npts = std::ceil((tau1 - tau0) / opts->step_size + 1.0f);
+            if (!(npts >= 2.f) || npts > 1e7f) return fail("%s: step_size gives an unusable grid (%g points)", who, npts);
+            if ((npts - 1.0f) * opts->step_size + tau0 < tau1)
+                return fail("%s: fixed grid does not reach t0 (torchdiffeq asserts time_grid[-1] == t[-1])", who);
+            a.n_grid = (int)npts - 1;
+        }
+    }
     if (!global) return fail("%s: the adjoint pass needs batch-global step control (tile_rows = 0)", who);
     const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
     if (hutch && !e) return fail("%s: Hutchinson divergence needs the probe e", who);
@@ -448,6 +468,13 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
         return 0;
     }
     hipError_t err = hipSuccess;
+    if (fixed) {
+        err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // the gradient slabs are accumulated into
+        if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        if (err == hipSuccess) err = cnf::launch_fixed_bwd(net->dim, hutch, a, s);
+        if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
+        return 0;
+    }
     if ((opts->flags & CNF_FLAG_CLEAN) && use_split(net, rows)) {
         // nothing to clear: granules and status are clean by contract, the slabs are stored (not accumulated) by the
         // first accepted step

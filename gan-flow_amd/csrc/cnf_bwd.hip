@@ -808,6 +808,135 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
     }
 }
 
+// ---- the adjoint solve on a fixed grid ------------------------------------------------------------------------
+// odeint_adjoint(..., method='euler' | 'midpoint' | 'rk4', options={'step_size': h}): the backward pass integrates the
+// augmented state (z, logp, a_z, a_logp, a_t, a_theta) from t1 back to t0 with the SAME fixed-grid method (torchdiffeq's
+// FixedGridODESolver on the negated time axis: grid points tau_i = -t1 + i h, the last clipped to -t0; no step control, so
+// no grid-wide reductions and any number of rows).  a_theta is one more state of that integration: its increment over a
+// step is the method's weighted sum of the stages' vjp_theta, i.e. the quadrature weights below (rk4 = the 3/8 rule's
+// dt/8 (1, 3, 3, 1); midpoint: the first stage only moves the state; euler: dt), accumulated over ALL steps in the
+// accumulators and stored once.  Same augmented evaluation (aug_eval) and the same time / sign conventions as
+// dopri5_bwd_kernel.  Parity unpinned (no reference artefact holds gradients): tests compare with the oracle's adjoint.
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void fixed_bwd_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
+    __shared__ NetLds<D> net;
+    __shared__ BwdNetLds netT;
+    __shared__ BwdWaveLds<D> wl[kNW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    constexpr int C = 2 * D + 1;   // z, logp, a_z
+    stage_net(net, a.params, tid);
+    stage_net_T<D>(netT, a.params, tid);
+    zero_slopes(wl, kNW, tid);
+    zero_small(wl[w], lane);
+    __syncthreads();
+    const long base = ((long)blockIdx.x * kNW + w) * kRows;
+    const long row = base + j;
+    const bool valid = row < a.rows;
+    const bool counted = valid && lane < 16;
+    const long rr = valid ? row : a.rows - 1;
+    BwdWaveLds<D>& ws = wl[w];
+    float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;   // this workgroup's partial of a_theta
+
+    float y[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+        y[D + 1 + m] = valid ? a.grad_z1[rr * D + m] : 0.f;   // padded rows carry zero adjoints: they add nothing to any sum
+    }
+    y[D] = a.logp0[rr];
+    const float al = valid ? a.grad_logp1[rr] : 0.f;   // d(a_logp)/dt = 0: constant along the solve
+    const int status = a.after ? a.after->status : 0;  // CnfSolverOpts.after: the solve whose output this one consumes failed
+
+    // the adjoint pass runs from t1 back to t0
+    const float sgn = a.t0 >= a.t1 ? 1.f : -1.f;
+    const float tau0 = sgn * a.t1, tau1 = sgn * a.t0;
+    const int nst = a.fixed_kind == CNF_SOLVER_EULER ? 1 : (a.fixed_kind == CNF_SOLVER_MIDPOINT ? 2 : 4);
+    BigAcc acc;
+    acc.zero();
+    int nrun = 0;
+    const int n_steps = status == 0 ? a.n_grid : 0;
+    for (int step = 0; step < n_steps; ++step) {
+        // grid point i = i*step_size + tau0 (product rounded before the add, like arange()*h + t0)
+        const float ta = a.n_grid == 1 ? tau0 : __fadd_rn(__fmul_rn((float)step, a.step_size), tau0);
+        const float tb = (step + 1 == a.n_grid) ? tau1 : __fadd_rn(__fmul_rn((float)(step + 1), a.step_size), tau0);
+        const float dt = tb - ta;
+        float k1[C], k2[C], k3[C], yi[C];
+        float ti = ta;
+#pragma unroll
+        for (int c = 0; c < C; ++c) yi[c] = y[c];
+        for (int st = 0; st < nst; ++st) {
+            float zz[D], az[D], f[D], vz[D], div, k[C];
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                zz[m] = yi[m];
+                az[m] = yi[D + 1 + m];
+            }
+            // weight of this stage's vjp_theta in the step's increment of a_theta
+            float wq;
+            if (a.fixed_kind == CNF_SOLVER_EULER) wq = dt;
+            else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) wq = st == 0 ? 0.f : dt;
+            else wq = (st == 0 || st == 3) ? dt / 8 : 3 * (dt / 8);
+            aug_eval<D, HUTCH>(net, netT, ws, lane, sgn * ti, zz, ee, az, al, sgn * wq, wq != 0.f, f, div, vz, acc, netT, w);
+#pragma unroll
+            for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+                f[m] = fmaf(-res, zz[m], f[m]);
+                vz[m] = fmaf(res, az[m], vz[m]);
+            }
+            div -= res * (float)D;
+            ++nrun;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                k[m] = sgn * f[m];
+                k[D + 1 + m] = sgn * vz[m];
+            }
+            k[D] = -sgn * div;
+            if (a.fixed_kind == CNF_SOLVER_EULER) {            // y + dt f(t, y)
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+            } else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) {  // y + dt f(t + dt/2, y + f(t, y) dt/2)
+                if (st == 0) {
+                    ti = ta + dt / 2;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) yi[c] = y[c] + k[c] * (dt / 2);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+                }
+            } else if (st == 0) {                              // the 3/8 rule, as rk4_kernel (cnf_fwd.hip)
+                ti = ta + dt / 3;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k1[c] = k[c]; yi[c] = y[c] + dt * k[c] / 3; }
+            } else if (st == 1) {
+                ti = ta + dt * 2 / 3;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k2[c] = k[c]; yi[c] = y[c] + dt * (k1[c] / -3 + k[c]); }
+            } else if (st == 2) {
+                ti = ta + dt;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k3[c] = k[c]; yi[c] = y[c] + dt * (k1[c] - k2[c] + k[c]); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + (k1[c] + 3 * k2[c] + 3 * k3[c] + k[c]) * (dt / 8);
+            }
+        }
+    }
+    if (status == 0 && counted) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) a.grad_x[row * D + m] = y[D + 1 + m];
+        a.grad_logp0[row] = al;
+    }
+    commit_step<D>(wl, acc, slab, tid);   // every wave of the workgroup (barriers inside); zero sums after a failed predecessor
+    if (lane == 0 && ((blockIdx.x == 0 && w == 0) || status != 0)) {
+        if (status) atomicMax(&a.stats->status, status);
+        atomicMax(&a.stats->nfe, nst * a.n_grid);
+        atomicMax(&a.stats->n_accepted, a.n_grid);
+        atomicMax(&a.stats->evals_run, nrun);
+        atomicAdd((unsigned long long*)&a.stats->row_evals, (unsigned long long)(a.rows * (long)nrun));
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------
 template <int D, bool HUTCH>
 static hipError_t launch_eval_aug_t(const SolveArgs& a, float t, const float* z, const float* a_z, const float* a_l,
@@ -850,6 +979,27 @@ hipError_t launch_solve_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
     if (D == 1 && !hutch) return launch_solve_bwd_t<1, false>(a, s);
     if (D == 2 && !hutch) return launch_solve_bwd_t<2, false>(a, s);
     if (D == 2 && hutch) return launch_solve_bwd_t<2, true>(a, s);
+    return hipErrorNotSupported;
+}
+
+template <int D, bool HUTCH>
+static hipError_t launch_fixed_bwd_t(const SolveArgs& a, hipStream_t s) {
+    const int grid = (int)((a.rows + kRowsPerWG - 1) / kRowsPerWG);
+    dbg_timing_begin(s);
+    hipLaunchKernelGGL((fixed_bwd_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    dbg_timing_end(s);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    const int P = make_layout(D, kH).total;
+    hipLaunchKernelGGL(reduce_slab_kernel, dim3((P + 255) / 256), dim3(256), 0, s, a.slab, grid, P, a.grad_params);
+    return hipGetLastError();
+}
+
+// fixed-grid adjoint (a.fixed_kind, a.n_grid, a.step_size as the forward fixed-grid solve reads them), hidden width 64, dim <= 2
+hipError_t launch_fixed_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s) {
+    if (D == 1 && !hutch) return launch_fixed_bwd_t<1, false>(a, s);
+    if (D == 2 && !hutch) return launch_fixed_bwd_t<2, false>(a, s);
+    if (D == 2 && hutch) return launch_fixed_bwd_t<2, true>(a, s);
     return hipErrorNotSupported;
 }
 

@@ -470,9 +470,10 @@ def main(argv=None):
                         residual=args.residual, batch_norm=args.batch_norm, bn_lag=args.bn_lag,
                         nonlinearity=args.nonlinearity).to(device)
     odenets = [blk.odefunc.odefunc.diffeq for blk in model.chain if isinstance(blk, CNF)]
-    if args.fused and (args.layer_type != "concatsquash" or args.batch_norm or any(n.is_padded() for n in odenets)):
+    if args.fused and (args.layer_type != "concatsquash" or args.batch_norm or any(n.is_padded() for n in odenets)
+                       or args.solver != "dopri5"):
         logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of concatsquash CNF blocks of hidden "
-                    "width 64 / 256 only)")
+                    "width 64 / 256 trained with dopri5 only; fixed-grid solvers train through cnf_solve_bwd's fixed-grid adjoint)")
         args.fused = 0
     for block in model.chain:
         if isinstance(block, CNF):

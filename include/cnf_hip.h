@@ -178,8 +178,11 @@ int cnf_eval_aug(const CnfNetDesc *net, const float *params, float t, const floa
 /* Backward solve: OdeintAdjointMethod.backward for the single interval [t0, t1] (a10).
  *   inputs : z1, logp1 = state at t1 saved by the forward; grad_z1, grad_logp1 = dL/d(state at t1)
  *   outputs: grad_x, grad_logp0 = dL/d(state at t0); grad_params (overwritten).
- *   Error control covers (z, logp) only, as the reference's length-2 tolerance lists imply; CNF_FLAG_ADJ_CONTROL_ALL
- *   adds (a_z, a_logp).                                                                            */
+ *   dopri5: error control covers (z, logp) only, as the reference's length-2 tolerance lists imply;
+ *   CNF_FLAG_ADJ_CONTROL_ALL adds (a_z, a_logp).
+ *   CNF_SOLVER_RK4 | EULER | MIDPOINT (hidden width 64, dim 1 | 2, at most 65 536 rows): the augmented state is integrated
+ *   backwards with the same fixed-grid method, the grid starting at t1 with spacing opts->step_size (<= 0: one step), as
+ *   odeint_adjoint(..., method=solver, options={'step_size': h}) does; stats: nfe = stages x steps, n_accepted = steps.  */
 int cnf_solve_bwd(const CnfNetDesc *net, const float *params, const float *z1, const float *logp1,
                   const float *e, const float *grad_z1, const float *grad_logp1, int64_t rows,
                   float t0, float t1, const CnfSolverOpts *opts, float *grad_x, float *grad_logp0,

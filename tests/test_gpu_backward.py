@@ -726,3 +726,56 @@ def test_other_nonlinearities(act, dim, hidden, hutch, rows):
     print("%s d=%d: adjoint attempts hip %d oracle %d, grad_theta %.2e grad_x %.2e" % (act, dim, nb, nb_ref, e_gp, e_gx))
     bar = 2e-4 if (nb == nb_ref and act != "elu") else 2e-3
     assert e_gp < bar and e_gx < bar
+
+
+@pytest.mark.parametrize("solver", ["rk4", "euler", "midpoint"])
+@pytest.mark.parametrize("dim,hutch,rows,step", [(2, False, 300, 0.1), (1, False, 70, None), (2, True, 128, 0.07), (2, False, 5000, 0.2)])
+def test_fixed_grid_adjoint_matches_oracle(solver, dim, hutch, rows, step):
+    """Training with a fixed-grid solver (`--solver rk4 | euler | midpoint [--step_size h]`):
+    odeint_adjoint integrates the augmented state backwards with the same method on the same kind of grid
+    (fixed_bwd_kernel, csrc/cnf_bwd.hip).  Loss, grad_x and grad_theta against the oracle's adjoint on identical weights and
+    inputs; both run the same arithmetic in fp32, so the bar is rounding level.  Parity unpinned: no reference artefact holds
+    gradients, the oracle restates torchdiffeq's fixed-grid solvers and adjoint as recalled."""
+    from gan_flow_amd import gu_ffjord
+    div = "approximate" if hutch else "brute_force"
+    mo = oracle_random_model(dim, seed=11, scale=1.5, divergence_fn=div, solver=solver)
+    mo.train()
+    mp = product_like(mo, DEV, divergence_fn=div, solver=solver)
+    opts = {"step_size": step} if step else {}
+    for blk in list(mo.chain) + list(mp.chain):
+        blk.solver_options = dict(opts)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, dim, generator=g) * 1.2
+    fo, fp = _odefunc(mo), mp.chain[0].odefunc.odefunc
+    if hutch:
+        e = torch.randn(rows, dim, generator=g)
+        orig, origp = fo.before_odeint, fp.before_odeint
+        fo.before_odeint = lambda e_=None: orig(e=e)
+        fp.before_odeint = lambda e_=None: origp(e=e.to(DEV))
+    loss_ref, z_ref, dl_ref, gx_ref, gp_ref, st_ref = _oracle_train_grads(mo, x)
+    xp = x.to(DEV).requires_grad_(True)
+    loss = gu_ffjord.compute_loss(mp, xp)
+    loss.backward()
+    gp = torch.cat([p.grad.reshape(-1) for p in fp.diffeq.parameters()])
+    st = mp.chain[0].last_stats
+    n_steps = st_ref["backward"]["n_steps"]
+    per_step = {"rk4": 4, "euler": 1, "midpoint": 2}[solver]
+    assert st["backward"].status == 0 and st["backward"].n_accepted == n_steps and st["backward"].nfe == per_step * n_steps
+    assert st["forward"].n_accepted == st_ref["forward"]["n_steps"]
+    e_gp, e_gx = rel_err(gp, gp_ref), rel_err(xp.grad, gx_ref)
+    print("%s d=%d rows=%d: %d steps, loss %.6f / %.6f, grad_theta %.2e grad_x %.2e" % (solver, dim, rows, n_steps, loss.item(), loss_ref, e_gp, e_gx))
+    assert abs(loss.item() - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    assert e_gp < 5e-5 and e_gx < 5e-5
+
+
+def test_fixed_grid_adjoint_limits():
+    """What the fixed-grid adjoint does not cover is refused with a message, before anything is launched."""
+    nat = _native()
+    for dim, hidden, hutch in ((16, 64, True), (2, 256, False)):
+        net = nat.net_desc(dim, hidden, 3, hutch)
+        n = nat.param_count(net)
+        p = torch.zeros(n, device=DEV)
+        z = torch.zeros(32, dim, device=DEV)
+        l = torch.zeros(32, 1, device=DEV)
+        with pytest.raises(nat.CnfError, match="fixed-grid adjoint"):
+            nat.solve_bwd(net, p, z, l, z, l, 0.0, 0.5, nat.make_opts("rk4", step_size=0.1), e=z if hutch else None)
