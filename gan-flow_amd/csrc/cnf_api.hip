@@ -14,6 +14,8 @@ hipError_t launch_eval_aug(int D, bool hutch, const SolveArgs& a, float t, const
                            const float* a_logp, float* f_out, float* nd_out, float* vjp_z_out, hipStream_t s);
 hipError_t launch_solve_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 hipError_t launch_fixed_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
+hipError_t launch_split16_fixed_bwd(const SolveArgs& a, hipStream_t s);
+hipError_t launch_wide_fixed_bwd(int D, bool hutch, const SolveArgs& a, float* ws_floats, hipStream_t s);
 // feature-split (one tile per workgroup) variants, cnf_split.hip
 hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
@@ -423,10 +425,7 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
     const bool fixed = opts->solver != CNF_SOLVER_DOPRI5;   // euler / midpoint / rk4: the adjoint runs on the same fixed grid, backwards
     if (fixed) {
         if (train) return fail("%s: built for dopri5; fixed-grid training goes through cnf_solve_bwd and cnf_adam_step", who);
-        if (is_wide(net) || net->dim > 2)
-            return fail("%s: the fixed-grid adjoint is built for hidden width 64 and dim <= 2 (got hidden %d, dim %d)", who,
-                        net->hidden, net->dim);
-        if (rows > kFixedBwdMaxRows)
+        if (!is_wide(net) && net->dim <= 2 && rows > kFixedBwdMaxRows)
             return fail("%s: the fixed-grid adjoint supports at most %ld rows per call (got %ld)", who, (long)kFixedBwdMaxRows, (long)rows);
         if (opts->step_size > 0.f) {
             // the grid of the backward solve starts at t1: torchdiffeq's grid constructor on the negated time axis
@@ -463,11 +462,21 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
             werr = hipMemsetAsync(workspace, 0, kGranBytes, s);   // the gradient slots are written before they are read
             if (werr == hipSuccess) werr = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
         }
-        if (werr == hipSuccess) werr = cnf::launch_wide_bwd(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), s);
+        if (werr == hipSuccess && fixed && (opts->flags & CNF_FLAG_CLEAN)) werr = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        if (werr == hipSuccess) werr = fixed ? cnf::launch_wide_fixed_bwd(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), s)
+                                             : cnf::launch_wide_bwd(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), s);
         if (werr != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(werr));
         return 0;
     }
     hipError_t err = hipSuccess;
+    if (fixed && net->dim > 2) {   // d = 16: one workgroup per tile (cnf_split16.hip), the slab is stored, not added to
+        const uintptr_t al = (uintptr_t)z1 | (uintptr_t)e | (uintptr_t)grad_z1 | (uintptr_t)grad_x | (uintptr_t)params;
+        if ((al & 15) != 0) return fail("%s: the fixed-grid adjoint at dim 16 needs 16-byte aligned z1, e, grad_z1, grad_x and params", who);
+        err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        if (err == hipSuccess) err = cnf::launch_split16_fixed_bwd(a, s);
+        if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
+        return 0;
+    }
     if (fixed) {
         err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // the gradient slabs are accumulated into
         if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);

@@ -1075,7 +1075,147 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
 }
 
+// ---- the adjoint on a fixed grid (euler / midpoint / rk4 3/8): what fixed_bwd_kernel (cnf_bwd.hip) is at d <= 2 -----------
+// One workgroup per tile, all sums in one set of accumulators over ALL steps (there are no rejected attempts), stored once.
+__global__ __launch_bounds__(kThreads) void fixed_bwd_split16_kernel(SolveArgs a) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
+    __shared__ Net16Lds net;
+    __shared__ Bwd16Lds sb;
+    __shared__ Xchg16B xc;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int pos = (j & 3) * 4 + (j >> 2);
+    stage_net16(net, a.params, tid);
+    stage_wimgT16<kD>(sb.wimgT16, a.params, tid);
+    SplitWeightsB16 wb;
+    load_weights_b16_global<kD>(wb, a.params, w, lane);
+    for (int i = tid; i < 7 * kCA * 64; i += kThreads) (&sb.kst[0][0][0])[i] = 0.f;
+    for (int i = tid; i < 4 * kSm16; i += kThreads) (&sb.small[0][0])[i] = 0.f;
+    const ParamLayout L = make_layout(kD, kH);
+    const f32x4 w1img = *reinterpret_cast<const f32x4*>(a.params + L.w(0) + (16 * w + j) * kD + 4 * q);
+    const f32x4 w4img = *reinterpret_cast<const f32x4*>(a.params + L.w(3) + j * kH + 16 * w + 4 * q);
+    f32x4 w1Timg, w4Timg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        w1Timg[r] = a.params[L.w(0) + (16 * w + 4 * q + r) * kD + j];
+        w4Timg[r] = a.params[L.w(3) + (4 * q + r) * kH + 16 * w + j];
+    }
+    const long row = (long)blockIdx.x * kRows + j;
+    const bool valid = row < a.rows;
+    const bool cz = valid && w == 0;
+    const bool cl = cz && q == 0;
+    const long rr = valid ? row : a.rows - 1;
+    float* slab = a.slab + (size_t)blockIdx.x * L.total;
+
+    float y[kCA];
+    const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.e + rr * kD + 4 * q);
+    {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(a.x + rr * kD + 4 * q);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.grad_z1 + rr * kD + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            y[r] = x4[r];
+            y[5 + r] = valid ? g4[r] : 0.f;
+            sb.tZ[1][(4 * q + r) * kRows + pos] = e4[r];
+        }
+    }
+    y[4] = a.logp0[rr];
+    const float al = valid ? a.grad_logp1[rr] : 0.f;
+    __syncthreads();
+
+    const int status = a.after ? a.after->status : 0;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    const float sgn = a.t0 >= a.t1 ? 1.f : -1.f;
+    const float tau0 = sgn * a.t1, tau1 = sgn * a.t0;   // the adjoint pass runs from t1 back to t0
+    const int nst = a.fixed_kind == CNF_SOLVER_EULER ? 1 : (a.fixed_kind == CNF_SOLVER_MIDPOINT ? 2 : 4);
+    Acc16<false> acc;
+    acc.zero();
+    int nrun = 0;
+    const int n_steps = status == 0 ? a.n_grid : 0;
+    for (int step = 0; step < n_steps; ++step) {
+        const float ta = a.n_grid == 1 ? tau0 : __fadd_rn(__fmul_rn((float)step, a.step_size), tau0);
+        const float tb = (step + 1 == a.n_grid) ? tau1 : __fadd_rn(__fmul_rn((float)(step + 1), a.step_size), tau0);
+        const float dt = tb - ta;
+        float k1[kCA], k2[kCA], k3[kCA], yi[kCA];
+        float ti = ta;
+#pragma unroll
+        for (int c = 0; c < kCA; ++c) yi[c] = y[c];
+        for (int st = 0; st < nst; ++st) {
+            f32x4 z4, az4, f4, vz4;
+            float div, k[kCA];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z4[r] = yi[r];
+                az4[r] = yi[5 + r];
+            }
+            float wq;   // weight of this stage's vjp_theta in the step's increment of a_theta
+            if (a.fixed_kind == CNF_SOLVER_EULER) wq = dt;
+            else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) wq = st == 0 ? 0.f : dt;
+            else wq = (st == 0 || st == 3) ? dt / 8 : 3 * (dt / 8);
+            aug_eval16(net, wb, sb, xc, w1img, w4img, w1Timg, w4Timg, lane, w, sgn * ti, z4, e4, az4, al, sgn * wq, wq != 0.f, f4, div,
+                       vz4, acc.dw(0), acc.dw(1), acc.thin(0), acc.thin(1), 0, 0, [](const f32x4&, float) {});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+                f4[r] = fmaf(-res, z4[r], f4[r]);
+                vz4[r] = fmaf(res, az4[r], vz4[r]);
+            }
+            div -= res * (float)kD;
+            ++nrun;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                k[r] = sgn * f4[r];
+                k[5 + r] = sgn * vz4[r];
+            }
+            k[4] = -sgn * div;
+            if (a.fixed_kind == CNF_SOLVER_EULER) {
+#pragma unroll
+                for (int c = 0; c < kCA; ++c) y[c] = y[c] + dt * k[c];
+            } else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) {
+                if (st == 0) {
+                    ti = ta + dt / 2;
+#pragma unroll
+                    for (int c = 0; c < kCA; ++c) yi[c] = y[c] + k[c] * (dt / 2);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < kCA; ++c) y[c] = y[c] + dt * k[c];
+                }
+            } else if (st == 0) {
+                ti = ta + dt / 3;
+#pragma unroll
+                for (int c = 0; c < kCA; ++c) { k1[c] = k[c]; yi[c] = y[c] + dt * k[c] / 3; }
+            } else if (st == 1) {
+                ti = ta + dt * 2 / 3;
+#pragma unroll
+                for (int c = 0; c < kCA; ++c) { k2[c] = k[c]; yi[c] = y[c] + dt * (k1[c] / -3 + k[c]); }
+            } else if (st == 2) {
+                ti = ta + dt;
+#pragma unroll
+                for (int c = 0; c < kCA; ++c) { k3[c] = k[c]; yi[c] = y[c] + dt * (k1[c] - k2[c] + k[c]); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < kCA; ++c) y[c] = y[c] + (k1[c] + 3 * k2[c] + 3 * k3[c] + k[c]) * (dt / 8);
+            }
+        }
+    }
+    if (status == 0) {
+        const f32x4 o = {y[5], y[6], y[7], y[8]};
+        if (cz) *reinterpret_cast<f32x4*>(a.grad_x + row * kD + 4 * q) = o;
+        if (cl) a.grad_logp0[row] = al;
+    }
+    commit16<false>(sb, acc, acc, acc, 0, 0, 0.f, 0.f, slab, tid, true, 0);   // stored, not added: one commit per solve
+    write_stats_global(a.stats, status, nst * a.n_grid, a.n_grid, 0, nrun, 0.f, a.rows, tid);
+}
+
 }  // namespace
+
+hipError_t launch_split16_fixed_bwd(const SolveArgs& a, hipStream_t s) {
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    dbg_timing_begin(s);
+    hipLaunchKernelGGL(fixed_bwd_split16_kernel, dim3(grid), dim3(kThreads), 0, s, a);
+    dbg_timing_end(s);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    const ParamLayout L = make_layout(kD, kH);
+    return launch_reduce_slab(a.slab, grid, L.total, a.grad_params, s, 0);
+}
 
 hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);

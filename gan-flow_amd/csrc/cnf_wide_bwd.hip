@@ -813,6 +813,121 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
     write_stats_global(a.stats, status, 2 + 6 * (nacc + nrej), nacc, nrej, nrun, (float)dt, a.rows, tid);
 }
 
+// ---- the adjoint on a fixed grid (euler / midpoint / rk4 3/8): what fixed_bwd_kernel (cnf_bwd.hip) is at hidden width 64 ----
+// Stage st of a step writes its unweighted d/dtheta sums to slot st; the step's commit folds them into the running total
+// with the method's weights (wide_commit, as an accepted dopri5 step does).  No step control: no grid-wide reductions.
+template <int D, bool HUTCH>
+__global__ __launch_bounds__(kThreads) void wide_fixed_bwd_kernel(SolveArgs a, const float* __restrict__ wt) {
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
+    constexpr int NS = (HUTCH ? 1 : D) + 1;
+    constexpr int C = 2 * D + 1;
+    __shared__ WideNetLds<D> net;
+    __shared__ WideWaveLds<C> wl[kNW];
+    __shared__ WideXchg<D, NS> xc;
+    __shared__ float part2[kNW][D][kRows];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    wide_stage_net(net, a.params, tid);
+    zero_slopes(wl, kNW, tid);
+    __syncthreads();
+    const long row = (long)blockIdx.x * kRows + j;
+    const bool valid = row < a.rows;
+    const bool counted = valid && lane < 16 && w == 0;
+    const long rr = valid ? row : a.rows - 1;
+    WideWaveLds<C>& ws = wl[w];
+    float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
+
+    float y[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+        y[D + 1 + m] = valid ? a.grad_z1[rr * D + m] : 0.f;
+    }
+    y[D] = a.logp0[rr];
+    const float al = valid ? a.grad_logp1[rr] : 0.f;
+    const int status = a.after ? a.after->status : 0;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    const float sgn = a.t0 >= a.t1 ? 1.f : -1.f;
+    const float tau0 = sgn * a.t1, tau1 = sgn * a.t0;   // the adjoint pass runs from t1 back to t0
+    const int nst = a.fixed_kind == CNF_SOLVER_EULER ? 1 : (a.fixed_kind == CNF_SOLVER_MIDPOINT ? 2 : 4);
+    int nrun = 0;
+    const int n_steps = status == 0 ? a.n_grid : 0;
+    for (int step = 0; step < n_steps; ++step) {
+        const float ta = a.n_grid == 1 ? tau0 : __fadd_rn(__fmul_rn((float)step, a.step_size), tau0);
+        const float tb = (step + 1 == a.n_grid) ? tau1 : __fadd_rn(__fmul_rn((float)(step + 1), a.step_size), tau0);
+        const float dt = tb - ta;
+        float k1[C], k2[C], k3[C], yi[C];
+        float ti = ta;
+        float wts[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) yi[c] = y[c];
+        for (int st = 0; st < nst; ++st) {
+            float zz[D], az[D], f[D], vz[D], div, k[C];
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                zz[m] = yi[m];
+                az[m] = yi[D + 1 + m];
+            }
+            float wq;   // weight of this stage's vjp_theta in the step's increment of a_theta
+            if (a.fixed_kind == CNF_SOLVER_EULER) wq = dt;
+            else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) wq = st == 0 ? 0.f : dt;
+            else wq = (st == 0 || st == 3) ? dt / 8 : 3 * (dt / 8);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) wts[s_] = st == s_ ? wq : wts[s_];
+            aug_eval_wide<D, HUTCH>(net, ws, xc, part2, a.params, wt, lane, w, sgn * ti, zz, ee, az, al, sgn, wq != 0.f, f, div, vz,
+                                    region + (size_t)st * kWideSlotF<D>, 0);
+#pragma unroll
+            for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+                f[m] = fmaf(-res, zz[m], f[m]);
+                vz[m] = fmaf(res, az[m], vz[m]);
+            }
+            div -= res * (float)D;
+            ++nrun;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                k[m] = sgn * f[m];
+                k[D + 1 + m] = sgn * vz[m];
+            }
+            k[D] = -sgn * div;
+            if (a.fixed_kind == CNF_SOLVER_EULER) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+            } else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) {
+                if (st == 0) {
+                    ti = ta + dt / 2;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) yi[c] = y[c] + k[c] * (dt / 2);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+                }
+            } else if (st == 0) {
+                ti = ta + dt / 3;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k1[c] = k[c]; yi[c] = y[c] + dt * k[c] / 3; }
+            } else if (st == 1) {
+                ti = ta + dt * 2 / 3;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k2[c] = k[c]; yi[c] = y[c] + dt * (k1[c] / -3 + k[c]); }
+            } else if (st == 2) {
+                ti = ta + dt;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { k3[c] = k[c]; yi[c] = y[c] + dt * (k1[c] - k2[c] + k[c]); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + (k1[c] + 3 * k2[c] + 3 * k3[c] + k[c]) * (dt / 8);
+            }
+        }
+        const int sl[7] = {0, 1, 2, 3, 4, 5, 6};
+        wide_commit<D>(region, sl, wts, step == 0, tid, 0);   // slots with weight zero are not read
+    }
+    if (status == 0 && counted) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) a.grad_x[row * D + m] = y[D + 1 + m];
+        a.grad_logp0[row] = al;
+    }
+    write_stats_global(a.stats, status, nst * a.n_grid, a.n_grid, 0, nrun, 0.f, a.rows, tid);
+}
+
 // sum slot `which` of every workgroup region in a fixed order and undo the block layout: out[canonical parameter index]
 template <int D>
 __global__ void wide_reduce_kernel(const float* __restrict__ regions, int nwg, int which, int valid, float* __restrict__ out,
@@ -887,6 +1002,33 @@ hipError_t launch_wide_bwd(int D, bool hutch, const SolveArgs& a, float* ws_floa
     if (D == 1 && !hutch) return wide_bwd_t<1, false>(a, ws_floats, s);
     if (D == 2 && !hutch) return wide_bwd_t<2, false>(a, ws_floats, s);
     if (D == 2 && hutch) return wide_bwd_t<2, true>(a, ws_floats, s);
+    return hipErrorNotSupported;
+}
+
+template <int D, bool HUTCH>
+static hipError_t wide_fixed_bwd_t(const SolveArgs& a0, float* ws_floats, hipStream_t s) {
+    SolveArgs a = a0;
+    float* wt = ws_floats;
+    a.slab = ws_floats + (size_t)2 * kWH * kWH;
+    hipError_t err = wide_prep(D, a.params, wt, s);
+    if (err != hipSuccess) return err;
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    dbg_timing_begin(s);
+    hipLaunchKernelGGL((wide_fixed_bwd_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a, (const float*)wt);
+    dbg_timing_end(s);
+    err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    const int P = make_layout(D, kWH).total;
+    hipLaunchKernelGGL((wide_reduce_kernel<D>), dim3((P + 255) / 256), dim3(256), 0, s, (const float*)a.slab, grid, kWideTotal, 1,
+                       a.grad_params, 0);
+    return hipGetLastError();
+}
+
+// fixed-grid adjoint at hidden width 256 (a.fixed_kind, a.n_grid, a.step_size), rows <= 4096
+hipError_t launch_wide_fixed_bwd(int D, bool hutch, const SolveArgs& a, float* ws_floats, hipStream_t s) {
+    if (D == 1 && !hutch) return wide_fixed_bwd_t<1, false>(a, ws_floats, s);
+    if (D == 2 && !hutch) return wide_fixed_bwd_t<2, false>(a, ws_floats, s);
+    if (D == 2 && hutch) return wide_fixed_bwd_t<2, true>(a, ws_floats, s);
     return hipErrorNotSupported;
 }
 

@@ -180,7 +180,8 @@ int cnf_eval_aug(const CnfNetDesc *net, const float *params, float t, const floa
  *   outputs: grad_x, grad_logp0 = dL/d(state at t0); grad_params (overwritten).
  *   dopri5: error control covers (z, logp) only, as the reference's length-2 tolerance lists imply;
  *   CNF_FLAG_ADJ_CONTROL_ALL adds (a_z, a_logp).
- *   CNF_SOLVER_RK4 | EULER | MIDPOINT (hidden width 64, dim 1 | 2, at most 65 536 rows): the augmented state is integrated
+ *   CNF_SOLVER_RK4 | EULER | MIDPOINT (hidden width 64: dim 1 | 2 up to 65 536 rows, dim 16 up to 4096 rows with 16-byte
+ *   aligned z1, e, grad_z1, grad_x and params; hidden width 256: up to 4096 rows): the augmented state is integrated
  *   backwards with the same fixed-grid method, the grid starting at t1 with spacing opts->step_size (<= 0: one step), as
  *   odeint_adjoint(..., method=solver, options={'step_size': h}) does; stats: nfe = stages x steps, n_accepted = steps.  */
 int cnf_solve_bwd(const CnfNetDesc *net, const float *params, const float *z1, const float *logp1,

@@ -768,14 +768,59 @@ def test_fixed_grid_adjoint_matches_oracle(solver, dim, hutch, rows, step):
     assert e_gp < 5e-5 and e_gx < 5e-5
 
 
+@pytest.mark.parametrize("solver", ["rk4", "euler", "midpoint"])
+@pytest.mark.parametrize("dim,hidden,hutch,rows,step", [(16, 64, True, 200, 0.1), (16, 64, True, 2048, None), (2, 256, False, 100, 0.125),
+                                                        (1, 256, False, 40, None), (2, 256, True, 64, 0.3)])
+def test_fixed_grid_adjoint_other_kernel_families(solver, dim, hidden, hutch, rows, step):
+    """The fixed-grid adjoint at d = 16 (fixed_bwd_split16_kernel, csrc/cnf_split16.hip) and at hidden width 256
+    (wide_fixed_bwd_kernel, csrc/cnf_wide_bwd.hip) against the oracle's adjoint, as test_fixed_grid_adjoint_matches_oracle."""
+    from gan_flow_amd import gu_ffjord
+    div = "approximate" if hutch else "brute_force"
+    dims = (hidden,) * 3
+    mo = oracle_random_model(dim, seed=13, scale=1.5 if hidden == 64 else 1.0, divergence_fn=div, solver=solver, hidden_dims=dims)
+    mo.train()
+    mp = gu_ffjord.build_model(dim, dims=dims, divergence_fn=div, solver=solver)
+    mp.load_state_dict(mo.state_dict())
+    mp = mp.to(DEV).train()
+    opts = {"step_size": step} if step else {}
+    for blk in list(mo.chain) + list(mp.chain):
+        blk.solver_options = dict(opts)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(rows, dim, generator=g) * 1.2
+    fo, fp = _odefunc(mo), mp.chain[0].odefunc.odefunc
+    if hutch:
+        e = torch.randn(rows, dim, generator=g)
+        orig, origp = fo.before_odeint, fp.before_odeint
+        fo.before_odeint = lambda e_=None: orig(e=e)
+        fp.before_odeint = lambda e_=None: origp(e=e.to(DEV))
+    loss_ref, z_ref, dl_ref, gx_ref, gp_ref, st_ref = _oracle_train_grads(mo, x)
+    xp = x.to(DEV).requires_grad_(True)
+    loss = gu_ffjord.compute_loss(mp, xp)
+    loss.backward()
+    gp = torch.cat([p.grad.reshape(-1) for p in fp.diffeq.parameters()])
+    st = mp.chain[0].last_stats
+    n_steps = st_ref["backward"]["n_steps"]
+    per_step = {"rk4": 4, "euler": 1, "midpoint": 2}[solver]
+    assert st["backward"].status == 0 and st["backward"].n_accepted == n_steps and st["backward"].nfe == per_step * n_steps
+    e_gp, e_gx = rel_err(gp, gp_ref), rel_err(xp.grad, gx_ref)
+    print("%s d=%d H=%d rows=%d: %d steps, loss %.6f / %.6f, grad_theta %.2e grad_x %.2e"
+          % (solver, dim, hidden, rows, n_steps, loss.item(), loss_ref, e_gp, e_gx))
+    assert abs(loss.item() - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
+    assert e_gp < 5e-5 and e_gx < 5e-5
+
+
 def test_fixed_grid_adjoint_limits():
     """What the fixed-grid adjoint does not cover is refused with a message, before anything is launched."""
     nat = _native()
-    for dim, hidden, hutch in ((16, 64, True), (2, 256, False)):
-        net = nat.net_desc(dim, hidden, 3, hutch)
-        n = nat.param_count(net)
-        p = torch.zeros(n, device=DEV)
-        z = torch.zeros(32, dim, device=DEV)
-        l = torch.zeros(32, 1, device=DEV)
-        with pytest.raises(nat.CnfError, match="fixed-grid adjoint"):
-            nat.solve_bwd(net, p, z, l, z, l, 0.0, 0.5, nat.make_opts("rk4", step_size=0.1), e=z if hutch else None)
+    net = nat.net_desc(16, 64, 3, True)
+    p = torch.zeros(nat.param_count(net), device=DEV)
+    z = torch.zeros(5000, 16, device=DEV)
+    l = torch.zeros(5000, 1, device=DEV)
+    with pytest.raises(nat.CnfError, match="at most"):      # d = 16: one workgroup per tile, <= 4096 rows
+        nat.solve_bwd(net, p, z, l, z, l, 0.0, 0.5, nat.make_opts("rk4", step_size=0.1), e=z)
+    net = nat.net_desc(2, 64, 3, False)
+    p = torch.zeros(nat.param_count(net), device=DEV)
+    z = torch.zeros(70000, 2, device=DEV)
+    l = torch.zeros(70000, 1, device=DEV)
+    with pytest.raises(nat.CnfError, match="fixed-grid adjoint supports at most"):
+        nat.solve_bwd(net, p, z, l, z, l, 0.0, 0.5, nat.make_opts("euler"))
