@@ -475,8 +475,8 @@ def test_solver_failures_and_bad_calls_are_reported(hidden):
             assert torch.equal(z[good.to(DEV)], z_ok[good.to(DEV)])
     # the adjoint refuses what it cannot do
     z1, l1, _ = nat.solve_fwd(net, params, x, None, 0.0, 0.5, ok)
-    with pytest.raises(nat.CnfError, match="dopri5 only"):
-        nat.solve_bwd(net, params, z1, l1, z1, l1, 0.0, 0.5, nat.make_opts("rk4", step_size=0.1))
+    with pytest.raises(nat.CnfError, match="unusable grid"):   # fixed-grid adjoints exist since round 2; their grid is checked
+        nat.solve_bwd(net, params, z1, l1, z1, l1, 0.0, 0.5, nat.make_opts("rk4", step_size=1e-9))
     with pytest.raises(nat.CnfError, match="batch-global"):
         nat.solve_bwd(net, params, z1, l1, z1, l1, 0.0, 0.5, nat.make_opts("dopri5", 1e-5, 1e-5, tile_rows=16))
 

@@ -148,6 +148,41 @@ def test_adjoint_gradients_match_autograd_through_unrolled_rk4():
     assert (g_adj - g_bp).abs().max() / g_bp.abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("solver,step,bar", [("rk4", 0.02, 1e-6), ("midpoint", 0.005, 2e-4), ("euler", 0.001, 5e-3)])
+def test_fixed_grid_adjoint_converges_to_backprop_through_the_same_solver(solver, step, bar):
+    """The oracle's fixed-grid adjoint (odeint_adjoint with method = euler | midpoint | rk4: what the kernels' fixed-grid
+    adjoint is held against) has no reference artefact either.  It integrates the adjoint ODE with the forward's method, which
+    is not the exact gradient of the discretised forward solve but converges to it with the method's order: float64, the
+    same grid, adjoint gradients against plain backprop through the unrolled solver."""
+    torch.manual_seed(2)
+    m = oracle.build_cnf(2, solver=solver).double()
+    x = torch.randn(8, 2, dtype=torch.float64) * 0.5
+    blk = m.chain[0]
+    blk.solver_options = {"step_size": step}
+
+    def loss_of(z, dl):
+        return -(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean()
+
+    m.train()
+    xa = x.clone().requires_grad_(True)
+    z, dl = m(xa, torch.zeros(8, 1, dtype=torch.float64))
+    m.zero_grad()
+    loss_of(z, dl).backward()
+    g_adj = torch.cat([p.grad.reshape(-1) for p in blk.odefunc.parameters()])
+    gx_adj = xa.grad.clone()
+    assert blk.stats["backward"]["n_steps"] == blk.stats["forward"]["n_steps"] == int(np.ceil(0.5 / step - 1e-9))
+    m.zero_grad()
+    xb = x.clone().requires_grad_(True)
+    zs, ls = oracle.odeint(blk.odefunc, (xb, torch.zeros(8, 1, dtype=torch.float64)),
+                           torch.tensor([0.0, float(blk.sqrt_end_time * blk.sqrt_end_time)]).double(), method=solver,   # fp32 end time, as CNF.forward forms it
+                           options=dict(step_size=step))
+    loss_of(zs[1], ls[1]).backward()
+    g_bp = torch.cat([p.grad.reshape(-1) for p in blk.odefunc.parameters()])
+    assert (z - zs[1]).abs().max() < 1e-12 and (dl - ls[1]).abs().max() < 1e-12
+    assert (g_adj - g_bp).abs().max() / g_bp.abs().max() < bar
+    assert (gx_adj - xb.grad).abs().max() / xb.grad.abs().max() < bar
+
+
 def test_adjoint_error_control_modes():
     """SURVEY Appendix D.3's switch in the oracle: 'state_only' (CNF's length-2 tolerance lists, zipped with the state
     tuple), 'rows' (+ a_z, a_logp; the kernels' CNF_FLAG_ADJ_CONTROL_ALL) and 'all' (+ a_t, a_theta; what scalar tolerances
