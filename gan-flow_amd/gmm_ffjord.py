@@ -27,6 +27,8 @@ def parse_args(argv=None):
     p.add_argument("--atol", type=float, default=1e-5)
     p.add_argument("--rtol", type=float, default=1e-5)
     p.add_argument("--rademacher", type=int, default=0)
+    p.add_argument("--solver", type=str, default="dopri5", choices=["dopri5", "rk4", "euler", "midpoint"])
+    p.add_argument("--step_size", type=float, default=None, help="fixed-grid solvers: grid spacing (default: one step over [0, T])")
     p.add_argument("--save", type=str, default="experiments/gmm_ffjord")
     return p.parse_args(argv)
 
@@ -42,15 +44,34 @@ def main(argv=None):
     logger.info(str(args))
     data = GaussianMixture(args.dim, device=device, sample_seed=args.seed)
     torch.manual_seed(args.seed)
-    model = build_model(args.dim, time_length=args.time_length, divergence_fn="approximate", atol=args.atol,
+    model = build_model(args.dim, time_length=args.time_length, divergence_fn="approximate", solver=args.solver, atol=args.atol,
                         rtol=args.rtol, rademacher=bool(args.rademacher)).to(device).train()
     logger.info("parameters: %d | data entropy (loss floor) %.4f" % (count_parameters(model), data.entropy_estimate()))
-    step = FusedTrainStep(model, data.get_sample(args.batch_size), lr=args.lr, weight_decay=args.weight_decay)
+    if args.solver == "dopri5":
+        step = FusedTrainStep(model, data.get_sample(args.batch_size), lr=args.lr, weight_decay=args.weight_decay)
+        check = step.check
+    else:
+        # fixed-grid training: autograd loop over cnf_solve_fwd / cnf_solve_bwd's fixed-grid adjoint (FusedTrainStep is dopri5 only)
+        for blk in model.chain:
+            if args.step_size:
+                blk.solver_options["step_size"] = args.step_size
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=True)
+
+        def step(x):
+            optimizer.zero_grad(set_to_none=True)
+            loss_ = compute_loss(model, x)
+            loss_.backward()
+            optimizer.step()
+            return loss_
+
+        def check():
+            st = model.chain[0].last_stats
+            return st["forward"].nfe, st["backward"].nfe
     t_last = time.time()
     for itr in range(1, args.niters + 1):
         loss = step(data.get_sample(args.batch_size))
         if itr % args.log_interval == 0 or itr == 1:
-            nfe_f, nfe_b = step.check()
+            nfe_f, nfe_b = check()
             now = time.time()
             logger.info("iter %06d | loss %.6f | NFE fwd %d bwd %d | %.4f s/iter" % (
                 itr, loss.item(), nfe_f, nfe_b, (now - t_last) / max(1, args.log_interval if itr > 1 else 1)))
