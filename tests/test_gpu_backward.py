@@ -824,3 +824,56 @@ def test_fixed_grid_adjoint_limits():
     l = torch.zeros(70000, 1, device=DEV)
     with pytest.raises(nat.CnfError, match="fixed-grid adjoint supports at most"):
         nat.solve_bwd(net, p, z, l, z, l, 0.0, 0.5, nat.make_opts("euler"))
+
+
+@pytest.mark.parametrize("solver,step", [("rk4", 0.004), ("midpoint", 0.002)])
+def test_fixed_grid_adjoint_on_the_trained_stiff_field(solver, step):
+    """The fixed-grid adjoint over MANY steps on the reference's trained gu_num=8 field (checkpoint weights, d = 1; the
+    regime config 2 lives in): 125 / 250 steps, sums accumulated in fp32 over all of them.  Bar as in the stiff dopri5 tests:
+    grad_theta no further from the float64 oracle (same method, same grid) than 2x the fp32 oracle is; grad_x (per row) by the
+    percentiles of its row errors against the fp32 oracle's own."""
+    import copy
+    from gan_flow_amd import gu_ffjord
+    mo = oracle_fixture_model("multimodal")
+    mo.train()
+    mp = product_like(mo, DEV)
+    m64 = copy.deepcopy(mo).double()
+    for m_ in (mo, mp, m64):
+        for blk in m_.chain:
+            blk.solver = solver
+            blk.solver_options = {"step_size": step}
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(96, 1, generator=g) * 76.0 + 7.0
+    loss_ref, _, _, gx_ref, gp_ref, st_ref = _oracle_train_grads(mo, x)
+    m64.zero_grad()
+    x64 = x.double().requires_grad_(True)
+    z64, dl64 = m64(x64, torch.zeros(96, 1, dtype=torch.float64))
+    _loss(z64, dl64).backward()
+    gp64 = torch.cat([p.grad.reshape(-1) for p in _odefunc(m64).diffeq.parameters()])
+    gx64 = x64.grad
+    xp = x.to(DEV).requires_grad_(True)
+    loss = gu_ffjord.compute_loss(mp, xp)
+    loss.backward()
+    gp = torch.cat([p.grad.reshape(-1) for p in mp.chain[0].odefunc.odefunc.diffeq.parameters()])
+    st = mp.chain[0].last_stats["backward"]
+    assert st.status == 0 and st.n_accepted == st_ref["backward"]["n_steps"]
+    d_hip_p, d_or_p = rel_err(gp, gp64), rel_err(gp_ref, gp64)
+    d_hip_x, d_or_x = rel_err(xp.grad, gx64), rel_err(gx_ref, gx64)
+    print("%s h=%g: %d steps | grad_theta vs float64: hip %.2e oracle-fp32 %.2e | grad_x: hip %.2e oracle-fp32 %.2e | hip vs oracle-fp32 %.2e %.2e"
+          % (solver, step, st.n_accepted, d_hip_p, d_or_p, d_hip_x, d_or_x, rel_err(gp, gp_ref), rel_err(xp.grad, gx_ref)))
+    # grad_x is a per-row quantity on a field that amplifies rounding differently row by row: state the distribution
+    sx = gx64.abs().max().item()
+    eh = ((xp.grad.cpu().double() - gx64).abs() / sx).reshape(-1)
+    eo = ((gx_ref.double() - gx64).abs() / sx).reshape(-1)
+    qs = torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64)
+    qh, qo = torch.quantile(eh, qs), torch.quantile(eo, qs)
+    print("   grad_x row errors / max|grad_x|, 50/90/99th percentile and max: hip %s %.2e | oracle-fp32 %s %.2e | worst rows hip %s oracle %s"
+          % (["%.1e" % v for v in qh.tolist()], eh.max().item(), ["%.1e" % v for v in qo.tolist()], eo.max().item(),
+             eh.argsort(descending=True)[:3].tolist(), eo.argsort(descending=True)[:3].tolist()))
+    assert d_hip_p <= 2 * d_or_p + 2e-6
+    # same quantile within 1.5x (median, 90th), tail and worst row bounded by 2x / 4x the oracle's: the worst row is one draw
+    # of rounding noise amplified by that row's trajectory (measured: rk4 5.3e-4 against 1.4e-4 in one row, midpoint 3.0e-4
+    # against 3.4e-4), the body of the distribution is what shows a systematic difference
+    assert qh[0] <= 1.5 * qo[0] + 2e-6 and qh[1] <= 1.5 * qo[1] + 2e-6 and qh[2] <= 2 * qo[2] + 2e-6
+    assert eh.max() <= 4 * eo.max() + 2e-6
+    assert abs(loss.item() - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
