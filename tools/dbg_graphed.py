@@ -23,6 +23,8 @@ for it in range(3):
         w = model.chain[0].last_stats[k]
         print(it, k, w.tolist() if torch.is_tensor(w) else w, w.data_ptr() if torch.is_tensor(w) else None)
     print("loss", loss.item())
+    if keep:
+        print("   captured blocks now:", {k: (v.tolist(), v.data_ptr()) for k, v in keep.items()})
     if it == 0:
         wd = gu_ffjord.evaluate_w_distance(model, data, 2000, device=dev)
         print("wd", wd, {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in model.chain[0].last_stats.items()})
