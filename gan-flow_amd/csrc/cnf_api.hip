@@ -69,6 +69,21 @@ int fail(const char* fmt, ...) {
     return 1;
 }
 
+// Clearing device memory before a launch: a kernel of our own, not hipMemsetAsync.  Under stream capture a memset becomes
+// a graph memset node, and a captured, unflagged solve replayed AFTER eager solves on the same device came back with a
+// non-zero status word (the words its kernel assigns were right; tools/dbg_graph_memset.py): the
+// node no longer cleared the block it was captured for.  A kernel node carries its arguments by value.  Every size
+// cleared here is a multiple of 4 bytes and every pointer 4-byte aligned (workspaces: 16).
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+hipError_t zero_async(void* p, int /*value: always 0*/, size_t bytes, hipStream_t s) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, (uint32_t*)p, n);
+    return hipGetLastError();
+}
 constexpr int64_t kFixedBwdMaxRows = 65536;   // fixed-grid adjoint: one gradient slab (37 KB) per 64 rows in the workspace
 constexpr size_t kGranBytes = 2 * (size_t)cnf::kMaxWG * 4 * sizeof(unsigned long long) + 64;  // 16 KiB of granules + the ticket word
 
@@ -291,8 +306,8 @@ int solve_fwd_impl(const char* who, bool library_scratch, const CnfNetDesc* net,
                        (is_wide(net) || use_split(net, rows));
     if (is_wide(net) && ((uintptr_t)params & 15) != 0) return fail("%s: params must be 16-byte aligned for hidden width 256", who);
     hipError_t err = hipSuccess;
-    if (!clean || library_scratch) err = hipMemsetAsync(workspace, 0, kGranBytes, s);
-    if (!clean && err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+    if (!clean || library_scratch) err = zero_async(workspace, 0, kGranBytes, s);
+    if (!clean && err == hipSuccess) err = zero_async(stats, 0, sizeof(CnfStats), s);
     if (err == hipSuccess) {
         if (is_wide(net)) err = cnf::launch_wide_solve(net->dim, hutch, a, opts->solver, global, s);
         else if (opts->solver == CNF_SOLVER_DOPRI5 && global && use_split(net, rows)) err = cnf::launch_split_fwd(net->dim, hutch, a, s);
@@ -391,7 +406,7 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
         if (werr != hipSuccess) return fail("cnf_eval_aug: launch failed: %s", hipGetErrorString(werr));
         return 0;
     }
-    hipError_t err = hipMemsetAsync(workspace, 0, need, s);   // granules + per-workgroup gradient slabs
+    hipError_t err = zero_async(workspace, 0, need, s);   // granules + per-workgroup gradient slabs
     if (err == hipSuccess) {
         if (use_split(net, rows)) err = cnf::launch_split_aug(net->dim, hutch, a, t, z, a_z, a_logp, f_out, neg_div_out, vjp_z_out, s);
         else err = cnf::launch_eval_aug(net->dim, hutch, a, t, z, a_z, a_logp, f_out, neg_div_out, vjp_z_out, s);
@@ -459,10 +474,10 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
         if (((uintptr_t)params & 15) != 0) return fail("%s: params must be 16-byte aligned for hidden width 256", who);
         hipError_t werr = hipSuccess;
         if (!(opts->flags & CNF_FLAG_CLEAN)) {
-            werr = hipMemsetAsync(workspace, 0, kGranBytes, s);   // the gradient slots are written before they are read
-            if (werr == hipSuccess) werr = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+            werr = zero_async(workspace, 0, kGranBytes, s);   // the gradient slots are written before they are read
+            if (werr == hipSuccess) werr = zero_async(stats, 0, sizeof(CnfStats), s);
         }
-        if (werr == hipSuccess && fixed && (opts->flags & CNF_FLAG_CLEAN)) werr = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        if (werr == hipSuccess && fixed && (opts->flags & CNF_FLAG_CLEAN)) werr = zero_async(stats, 0, sizeof(CnfStats), s);
         if (werr == hipSuccess) werr = fixed ? cnf::launch_wide_fixed_bwd(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), s)
                                              : cnf::launch_wide_bwd(net->dim, hutch, a, (float*)((char*)workspace + kGranBytes), s);
         if (werr != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(werr));
@@ -472,14 +487,14 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
     if (fixed && net->dim > 2) {   // d = 16: one workgroup per tile (cnf_split16.hip), the slab is stored, not added to
         const uintptr_t al = (uintptr_t)z1 | (uintptr_t)e | (uintptr_t)grad_z1 | (uintptr_t)grad_x | (uintptr_t)params;
         if ((al & 15) != 0) return fail("%s: the fixed-grid adjoint at dim 16 needs 16-byte aligned z1, e, grad_z1, grad_x and params", who);
-        err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        err = zero_async(stats, 0, sizeof(CnfStats), s);
         if (err == hipSuccess) err = cnf::launch_split16_fixed_bwd(a, s);
         if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
         return 0;
     }
     if (fixed) {
-        err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // the gradient slabs are accumulated into
-        if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        err = zero_async(workspace, 0, cnf_workspace_bytes(net, rows), s);   // the gradient slabs are accumulated into
+        if (err == hipSuccess) err = zero_async(stats, 0, sizeof(CnfStats), s);
         if (err == hipSuccess) err = cnf::launch_fixed_bwd(net->dim, hutch, a, s);
         if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
         return 0;
@@ -488,11 +503,11 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
         // nothing to clear: granules and status are clean by contract, the slabs are stored (not accumulated) by the
         // first accepted step
     } else if (use_split(net, rows)) {
-        err = hipMemsetAsync(workspace, 0, kGranBytes, s);
-        if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        err = zero_async(workspace, 0, kGranBytes, s);
+        if (err == hipSuccess) err = zero_async(stats, 0, sizeof(CnfStats), s);
     } else {
-        err = hipMemsetAsync(workspace, 0, cnf_workspace_bytes(net, rows), s);   // granules + gradient slabs
-        if (err == hipSuccess) err = hipMemsetAsync(stats, 0, sizeof(CnfStats), s);
+        err = zero_async(workspace, 0, cnf_workspace_bytes(net, rows), s);   // granules + gradient slabs
+        if (err == hipSuccess) err = zero_async(stats, 0, sizeof(CnfStats), s);
     }
     if (err == hipSuccess) err = use_split(net, rows) ? cnf::launch_split_bwd(net->dim, hutch, a, s) : cnf::launch_solve_bwd(net->dim, hutch, a, s);
     if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));

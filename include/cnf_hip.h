@@ -13,7 +13,8 @@
  *   - every pointer is a BORROWED DEVICE pointer (fp32, contiguous row-major) unless marked "host";
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *   - the library never allocates device memory: the caller passes a workspace of
- *     cnf_workspace_bytes() bytes (16-byte aligned) that the call zeroes and uses (see CNF_FLAG_CLEAN);
+ *     cnf_workspace_bytes() bytes (16-byte aligned) that the call zeroes (with a kernel, never a memset node) and uses
+ *     (see CNF_FLAG_CLEAN);
  *   - return value 0 = enqueued; non-zero = rejected before launch, message in cnf_last_error();
  *   - run-time failures of the integrator (step underflow, non-finite state, step limit) are
  *     reported in CnfStats.status, which lives in device memory and is read by the caller after
@@ -153,8 +154,8 @@ int cnf_solve_fwd(const CnfNetDesc *net, const float *params, const float *x, co
  * cnf_solve_fwd -- bit-identical outputs and stats -- minus `workspace`: the granules of the grid-wide reductions (and, at
  * hidden width 256, the bf16 pieces of the two hidden matrices) live in a file-scope device array inside the library,
  * cnf_static_scratch_bytes() = 802 880 bytes per GPU the library has run on, held until the process ends.
- * The call allocates nothing (no hipMalloc / hipFree, no allocating library routine); it enqueues one memset of the first
- * 16 448 bytes of that array and the solve kernel(s).  The array's per-device address is looked up on the first call on
+ * The call allocates nothing (no hipMalloc / hipFree, no allocating library routine); it enqueues one clear of the first
+ * 16 448 bytes of that array (a kernel of the library's own, so that it is a kernel node under capture) and the solve kernel(s).  The array's per-device address is looked up on the first call on
  * each device (hipGetSymbolAddress): make that first call outside stream capture.
  * Limits: those of cnf_solve_fwd (batch-global control: <= 4096 rows at hidden width 256, <= 16 384 at 64; tile-local and
  * fixed-grid: any number of rows); a solve whose scratch need exceeds the array is rejected with a message.

@@ -493,3 +493,42 @@ def test_other_fixed_grid_solvers_parity(solver, dim, hutch, rows):
     (z_ref, l_ref, _), (z, l, st) = _solve_pair(m, x, False, solver, step_size=0.02, hutch=hutch, e=e)
     assert rel_err(z, z_ref) < 1e-5 and rel_err(l, l_ref) < 1e-5
     assert st.nfe == (1 if solver == "euler" else 2) * st.n_accepted == (1 if solver == "euler" else 2) * 25
+
+
+def test_captured_unflagged_solve_survives_eager_solves_between_replays():
+    """A solve without CNF_FLAG_CLEAN clears its granules and stats block before the launch.  Captured into a hipGraph, a
+    hipMemsetAsync there becomes a graph memset node, and such a node stopped clearing the block it was captured for once
+    eager solves (eager memsets) had run between replays: the replayed solve came back with a non-zero status word.  The
+    library clears with a kernel of its own (zero_async, csrc/cnf_api.hip): replays before and after eager work must agree
+    bit for bit and report status 0.  Also covers GraphedTrainStep's pattern (captured autograd loop + eager evaluation)."""
+    nat = _native()
+    m = oracle_random_model(2, seed=3, scale=2.0)
+    net, params = nat.net_desc(2, 64, 3, False), _flat(m).to(DEV)
+    g_ = torch.Generator().manual_seed(2)
+    x = torch.randn(2048, 2, generator=g_).to(DEV)
+    xe = torch.randn(2000, 2, generator=g_).to(DEV)
+    opts = nat.make_opts("dopri5", 1e-5, 1e-5)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        z_ref, l_ref, st_ref = nat.solve_fwd(net, params, x, None, 0.0, 0.5, opts)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        z1, l1, st = nat.solve_fwd(net, params, x, None, 0.0, 0.5, opts)
+    for phase in range(3):
+        z1.fill_(float("nan"))
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        s = nat.Stats(st)
+        assert s.status == 0 and (s.nfe, s.n_accepted, s.n_rejected) == tuple(nat.Stats(st_ref).__dict__[k] for k in ("nfe", "n_accepted", "n_rejected")), (phase, s)
+        assert torch.equal(z1, z_ref) and torch.equal(l1, l_ref), phase
+        if phase == 0:      # eager solves of another size, on the default stream
+            for _ in range(2):
+                nat.solve_fwd(net, params, xe, None, 0.0, 0.5, opts)
+        elif phase == 1:    # eager torch work that fills and frees memory
+            torch.sort(torch.randn(100000, device=DEV))
+            torch.zeros(1 << 20, device=DEV)
+        torch.cuda.synchronize()
