@@ -109,6 +109,7 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may call HIP
             self.static_loss = self._eager()
             st = [model.chain[0].last_stats["forward"], model.chain[0].last_stats["backward"]]
+            self._captured_stats = [(blk, dict(blk.last_stats)) for blk in model.chain]
             self.nfe += torch.stack([st[0][1], st[1][1]]).to(torch.int64)
 
     def _eager(self):
@@ -126,11 +127,16 @@ class GraphedTrainStep:
     def check(self):
         """Read the solver status words back (one sync) and raise what the eager path would have raised."""
         from . import _native
-        for blk in self.model.chain:
-            for key in ("forward", "backward"):
-                words = blk.last_stats.get(key)
+        nfe = [0, 0]
+        # the captured iteration's own blocks when there are any: eager solves in between (evaluation) replace blk.last_stats
+        for blk, stats in getattr(self, "_captured_stats", None) or [(b, b.last_stats) for b in self.model.chain]:
+            for i, key in enumerate(("forward", "backward")):
+                words = stats.get(key)
                 if torch.is_tensor(words):
-                    _native.Stats(words).raise_for_status()
+                    st = _native.Stats(words)
+                    st.raise_for_status()
+                    nfe[i] += st.nfe
+        self.last_nfe = tuple(nfe)
 
 
 class FusedTrainStep:
@@ -448,6 +454,9 @@ def parse_args(argv=None):
     p.add_argument("--eval_logp_size", type=int, default=20000, help="fresh data points for the E[log p] estimate at log points")
     p.add_argument("--fused", type=int, default=1, help="1: FusedTrainStep (library kernels only, one hipGraph replay per "
                    "iteration); 0: autograd + torch.optim.Adam loop")
+    p.add_argument("--graphed", type=int, default=0, help="with --fused 0 (or a configuration FusedTrainStep does not cover, e.g. a "
+                   "fixed-grid --solver): 1 = capture the autograd + Adam iteration as one hipGraph (GraphedTrainStep) instead of "
+                   "launching it eagerly; needs a model without host-side state in its forward (no --batch_norm) and no --resume")
     p.add_argument("--device_sampler", type=int, default=1, help="1: draw the training and evaluation data on the GPU "
                    "(cnf_gu_sample, same distribution as gu.py's host sampler, another random stream); 0: the reference's "
                    "numpy sampler on the host + a copy per iteration")
@@ -482,17 +491,22 @@ def main(argv=None):
                 block.solver_options["step_size"] = args.step_size
     logger.info("parameters: %d" % count_parameters(model))
     model.train()
-    fused = optimizer = None
+    fused = optimizer = graphed = None
     on_device = data.device_sampler(device) if args.device_sampler else None
     train_sampler = on_device if (args.fused and on_device is not None) else None
     if args.fused:
         x = data.get_sample(args.batch_size).to(device)
         fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay, sampler=train_sampler)
     else:
-        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=True)
+        graphed_ok = bool(args.graphed) and not args.batch_norm and not args.resume
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
+                                     **(dict(capturable=True) if graphed_ok else dict(fused=True)))
         for block in model.chain:          # one training per GPU: the adjoint may use both halves of the chip
             if isinstance(block, CNF):
                 block.spread_adjoint = True
+        if graphed_ok:
+            x = (on_device or data).get_sample(args.batch_size).to(device)
+            graphed = GraphedTrainStep(model, optimizer, x, warmup_batches=[x])
     start_itr = 0
     if args.resume:
         ck = torch.load(args.resume, map_location=device, weights_only=True)
@@ -536,6 +550,11 @@ def main(argv=None):
             loss = fused(x)
             if log_now:
                 nfe_f, nfe_b = fused.check()
+        elif graphed is not None:
+            loss = graphed(x)
+            if log_now:
+                graphed.check()
+                nfe_f, nfe_b = graphed.last_nfe
         else:
             optimizer.zero_grad(set_to_none=True)
             loss = compute_loss(model, x)
@@ -557,6 +576,8 @@ def main(argv=None):
             torch.cuda.synchronize()
             if fused is not None:
                 fused.check()          # never overwrite the last good checkpoint after a failed solve
+            if graphed is not None:
+                graphed.check()
             checkpoint(itr)
             logger.info("time limit reached at iteration %d: checkpoint written" % itr)
             break
