@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--batch", type=int, default=2048)
     p.add_argument("--eval-rows", type=int, default=1 << 24,
                    help="rows of the sharded log-likelihood evaluation and of the sharded sampling (BASELINE config 3: 2^24)")
-    p.add_argument("--late-steps", type=int, default=3)
+    p.add_argument("--late-steps", type=int, default=10)
     p.add_argument("--cpu-iters", type=int, default=30, help="iterations per pass of the cpu_baseline window (rank 0, N=1)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time to spend on the cpu_baseline sample")
     p.add_argument("--mode", type=str, default="fused", choices=["fused", "graph", "eager"],
@@ -276,6 +276,7 @@ def main():
         out["config1"] = measure_config1(ctx)
     if "roofline" in extras and rank == 0:
         out["roofline"] = measure_roofline(ctx)
+        out["roofline_forward"] = forward_roofline(ctx["model"], ctx["batches"][-1])
     if "late" in extras:
         out["late_training"] = measure_late(ctx)
     if "eval" in extras:
@@ -319,18 +320,25 @@ def measure_late(ctx):
     ctx["barrier"]()
     t0 = time.perf_counter()
     lf = lb = 0
+    per_step = []
     for i in range(args.late_steps):
-        step(batches[1 + i])
-        f, b = step.check()
+        t1 = time.perf_counter()
+        step(batches[1 + i % (len(batches) - 1)])
+        f, b = step.check()          # one host sync per step: it is ~16 ms long, the sync costs ~10 us
+        per_step.append(1e3 * (time.perf_counter() - t1))
         lf += f
         lb += b
     ctx["barrier"]()
     lel = ctx["max_over_ranks"](time.perf_counter() - t0)
+    per_step.sort()
     res = {"value": round(world * args.late_steps / lel, 4), "unit": "iters/s", "ms_per_step": round(1e3 * lel / args.late_steps, 2),
+           "steps": args.late_steps, "rank0_ms_per_step_min": round(per_step[0], 2),
+           "rank0_ms_per_step_median": round(per_step[len(per_step) // 2], 2), "rank0_ms_per_step_max": round(per_step[-1], 2),
            "mean_nfe_forward": round(lf / args.late_steps, 1), "mean_nfe_backward": round(lb / args.late_steps, 1),
            "workload": "same step on the reference's trained gu_num=8 field (checkpoint weights embedded in d=2)"}
     if rank == 0:
         res["roofline"] = adjoint_roofline(late, batches[1], ctx["spread"], reps=3)
+        res["roofline_forward"] = forward_roofline(late, batches[1], reps=3)
         if world == 1 and args.cpu_late_iters > 0 and "cpu" in set(args.extras.split(",")):
             # the CPU oracle on the same field and batches: where BASELINE config 2 spends > 99 % of its iterations
             import oracle
@@ -393,6 +401,34 @@ def adjoint_roofline(model, x, spread, reps=20):
             "flop_per_launch": flops,
             "peak_note": "dense fp32 matrix peak (the hidden-layer products run on the bf16 pipe with three-piece operands: six "
                          "bf16 MFMAs of 16 clocks do the work of sixteen fp32 ones of 32; FLOP are counted as fp32 work)"}
+
+
+def forward_roofline(model, x, reps=20):
+    """The forward solve kernel of the timed step, as adjoint_roofline: rows x NFE x F_eval / mean kernel duration (HIP events
+    recorded by the library around the kernel).  It is the kernel furthest below its roof: 128 workgroups on 256 compute units,
+    one wave per SIMD, a dependent chain per evaluation."""
+    from gan_flow_amd import _native
+    blk = model.chain[0]
+    fn = blk.odefunc.odefunc
+    net = fn.net_desc()
+    params = fn.diffeq.flat_parameters().detach()
+    opts = _native.make_opts("dopri5", blk.rtol, blk.atol)
+    T = float(blk.sqrt_end_time.detach() ** 2)
+    rows = x.shape[0]
+    _native.solve_fwd(net, params, x, None, 0.0, T, opts)
+    _native.kernel_timing(True)
+    ms = 0.0
+    for _ in range(reps):
+        st = _native.solve_fwd(net, params, x, None, 0.0, T, opts)[2]
+        ms += _native.last_kernel_ms() / reps
+    _native.kernel_timing(False)
+    st = _native.Stats(st)
+    flops = rows * st.nfe * F_EVAL_D2
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "dopri5_split_kernel<2,false>", "achieved": round(achieved, 4), "peak": PEAK_FP32_MATRIX_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5), "launch_ms": round(ms, 4), "nfe": st.nfe,
+            "us_per_evaluation": round(1e3 * ms / st.nfe, 3), "flop_per_launch": flops,
+            "peak_note": "dense fp32 matrix peak; FLOP counted as fp32 work (hidden layers on the bf16 pipe, three-piece operands)"}
 
 
 def measure_config1(ctx):
@@ -559,13 +595,18 @@ def measure_eval(ctx):
     em = em.to(dev).eval()
     for b in em.chain:
         b.tile_rows = 16
+    # Config 3's points, addressed by GLOBAL row index (cnf_gu_sample_rows: counter-based, stateless): rows [0, N/2) are draws of
+    # the training distribution, rows [N/2, N) of N(45, 23^2) (the tails).  Every world size evaluates the SAME N rows, so
+    # mean_log_likelihood is comparable between the N = 1, 2, 4, 8 runs of a scaling sweep (to summation order).
+    from gan_flow_amd.gu import DeviceNormalRows, make_gu
     lo, hi = parallel_eval.shard_bounds(args.eval_rows, rank, world)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
     n_loc = hi - lo
-    half = n_loc // 2
-    comp = torch.randint(0, 8, (half,), generator=g, device=dev).float() * 10 + 10
-    xs = torch.cat([comp + (torch.rand(half, generator=g, device=dev) * 6 - 3),
-                    45 + 23 * torch.randn(n_loc - half, generator=g, device=dev)]).reshape(-1, 1)
+    n_data = args.eval_rows // 2
+    mix = make_gu(8, device="cpu", seed=1234, extend_dim=False).device_sampler(dev)
+    tails = DeviceNormalRows(dev, seed=4321, mean=45.0, sigma=23.0)
+    xs = torch.cat([mix.get_rows(min(lo, n_data), min(hi, n_data)),
+                    tails.get_rows(max(lo, n_data) - n_data, max(hi, n_data) - n_data)])
+    assert xs.shape == (n_loc, 1)
     work = {"row_evals": 0, "nfe_max": 0}
 
     def lp(v):
@@ -591,10 +632,18 @@ def measure_eval(ctx):
         del xs
         ctx["barrier"]()
         t0 = time.perf_counter()
-        smp = parallel_eval.sharded_sample(sample_fn, args.eval_rows, 1, rank, world, dev, seed=7, chunk=EVAL_LAUNCH_ROWS)
+        prior = DeviceNormalRows(dev, seed=7)
+        smp = parallel_eval.sharded_sample(sample_fn, args.eval_rows, 1, rank, world, dev, chunk=EVAL_LAUNCH_ROWS,
+                                           prior_rows=lambda a, b: prior.get_rows(a, b))
         ctx["barrier"]()
         sel = ctx["max_over_ranks"](time.perf_counter() - t0)
         smp_mean = smp.double().mean().item()
+        # the study's metric over ALL ranks' samples (model_plot.py:93-101, util.py:16-20): generated vs. fresh data rows
+        t0 = time.perf_counter()
+        real = mix.get_rows(lo, hi, call=1)
+        wd = parallel_eval.sharded_w_distance(real, smp, args.eval_rows, args.eval_rows)
+        ctx["barrier"]()
+        wel = ctx["max_over_ranks"](time.perf_counter() - t0)
     tfl = ll_evals * F_EVAL_D1 / eel / 1e12
     return {"value": round(rows / eel, 1), "unit": "samples/s", "rows": rows, "scaling": "strong",
             "mean_log_likelihood": round(mean_lp, 5), "rank0_mean_nfe": round(ll_evals / max(1, n_loc), 1),
@@ -602,7 +651,10 @@ def measure_eval(ctx):
             "rank0_tflops": round(tfl, 3),
             "roofline": eval_roofline(tfl),
             "sampling": {"value": round(args.eval_rows / sel, 1), "unit": "samples/s", "rows": args.eval_rows,
-                         "rank0_sample_mean": round(smp_mean, 4)},
+                         "rank0_sample_mean": round(smp_mean, 4), "w_distance": wd, "w_distance_s": round(wel, 3),
+                         "w_distance_note": "1-D Wasserstein distance of ALL ranks' samples against as many fresh data rows "
+                                            "(two all_gathers + sort on every rank); not in the timed sampling region"},
+            "data": "points and prior draws addressed by global row index (cnf_gu_sample_rows): identical for every world size",
             "workload": "log-likelihood of %d synthetic points, then %d samples, under the trained gu_num=8 CNF (d=1 "
                         "checkpoint), tile-local dopri5 1e-5, batch-sharded, one all-reduce of 2 x f64"
                         % (rows, args.eval_rows)}
@@ -614,9 +666,12 @@ def eval_roofline(tflops):
     limit is vector-instruction issue.  `valu_issue.busy_frac` = SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / waves per SIMD)
     from this round's rocprofv3 --pmc pass over tools/time_eval.py (profiles/): not measurable in-process."""
     import glob
-    out = {"bound": "mfma", "kernel": "dopri5_kernel<1,false,false,4,true>", "achieved": round(tflops, 3), "peak": PEAK_FP32_MATRIX_TFLOPS,
-           "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP32_MATRIX_TFLOPS, 4),
-           "peak_note": "dense fp32 matrix peak; FLOP counted as fp32 work (the kernel's hidden layers run on the bf16 pipe)",
+    out = {"bound": "valu_issue", "kernel": "dopri5_kernel<1,false,false,4,true>", "achieved": None, "peak": 1.0,
+           "unit": "busy fraction of the vector ALU's issue slots", "frac": None,
+           "fp32_equivalent": {"achieved": round(tflops, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tflops / PEAK_FP32_MATRIX_TFLOPS, 4),
+                               "note": "yardstick only: FLOP counted as fp32 work against the dense fp32 matrix peak; the kernel's "
+                                       "hidden layers run on the bf16 pipe, which is not what bounds it"},
            "valu_issue": None}
     path = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_eval_sq_pmc_summary.txt"))) or [""])[-1]
     if os.path.exists(path):
@@ -632,6 +687,7 @@ def eval_roofline(tflops):
             out["valu_issue"] = {"busy_frac": round(tot["SQ_ACTIVE_INST_VALU"] / (tot["SQ_WAVE_CYCLES"] / waves_per_simd), 3),
                                  "valu_per_mfma": round(tot.get("SQ_INSTS_VALU", 0.0) / max(1.0, tot.get("SQ_INSTS_MFMA", 1.0)), 2),
                                  "source": os.path.relpath(path, ROOT)}
+            out["achieved"] = out["frac"] = out["valu_issue"]["busy_frac"]
     return out
 
 

@@ -52,7 +52,7 @@ STATUS_MESSAGES = {
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
            "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
            "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation", "cnf_debug_eval_field_b16",
-           "cnf_solve_fwd_static", "cnf_static_scratch_bytes", "cnf_gu_sample")
+           "cnf_solve_fwd_static", "cnf_static_scratch_bytes", "cnf_gu_sample", "cnf_gu_sample_rows")
 
 
 def library_path(act="tanh"):
@@ -93,6 +93,8 @@ def load_library(act="tanh"):
     lib.cnf_static_scratch_bytes.argtypes = []
     lib.cnf_gu_sample.restype = ctypes.c_int
     lib.cnf_gu_sample.argtypes = [ctypes.POINTER(CnfGuDesc), ctypes.c_uint64, P, I64, P, VP]
+    lib.cnf_gu_sample_rows.restype = ctypes.c_int
+    lib.cnf_gu_sample_rows.argtypes = [ctypes.POINTER(CnfGuDesc), ctypes.c_uint64, ctypes.c_uint32, I64, I64, P, VP]
     lib.cnf_eval_aug.restype = ctypes.c_int
     lib.cnf_eval_aug.argtypes = [ND, P, F, P, P, P, P, I64, P, P, P, P, VP, SZ, VP]
     lib.cnf_solve_bwd.restype = ctypes.c_int
@@ -433,6 +435,22 @@ def gu_sample(desc, seed, state, out):
     with torch.cuda.device(out.device):
         _check(lib.cnf_gu_sample(ctypes.byref(desc), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(state), out.shape[0], _ptr(out),
                                  _stream()), lib)
+    return out
+
+
+def gu_sample_rows(desc, seed, call, row0, out):
+    """cnf_gu_sample_rows: rows row0 .. row0 + len(out) - 1 of draw number `call`, addressed by global row index (stateless:
+    a shard of a data set holds the same values for every number of shards)."""
+    lib = load_library()
+    cols = 2 if desc.extend_dim else 1
+    if not (torch.is_tensor(out) and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.dim() == 2
+            and out.shape[1] == cols):
+        raise CnfError("out must be a contiguous fp32 (rows, %d) tensor on the HIP device" % cols)
+    if out.shape[0] == 0:
+        return out
+    with torch.cuda.device(out.device):
+        _check(lib.cnf_gu_sample_rows(ctypes.byref(desc), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.c_uint32(int(call) & 0xFFFFFFFF),
+                                      int(row0), out.shape[0], _ptr(out), _stream()), lib)
     return out
 
 

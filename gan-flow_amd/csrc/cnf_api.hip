@@ -29,6 +29,8 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int* state,
 hipError_t launch_fill_lds(unsigned pattern, unsigned* sink, hipStream_t s);
 // training data on the device, cnf_data.hip
 hipError_t launch_gu_sample(const CnfGuDesc& d, unsigned long long seed, int* state, long rows, float* out, hipStream_t s);
+hipError_t launch_gu_sample_rows(const CnfGuDesc& d, unsigned long long seed, unsigned call, long row0, long rows, float* out,
+                                 hipStream_t s);
 // hidden width 256, forward path (cnf_wide.hip)
 hipError_t launch_wide_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
                              float* f_out, float* nd_out, hipStream_t s, float res);
@@ -582,6 +584,25 @@ int cnf_gu_sample(const CnfGuDesc* gu, uint64_t seed, int32_t* state, int64_t ro
             return fail("cnf_gu_sample: component %d: need sigma > 0, unif_intsect >= 0, 0 <= unif_p <= 1, finite mean", c);
     hipError_t err = cnf::launch_gu_sample(*gu, seed, state, rows, out, (hipStream_t)stream);
     if (err != hipSuccess) return fail("cnf_gu_sample: launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+static int check_gu(const char* who, const CnfGuDesc* gu) {
+    if (gu->n_mixture < 1 || gu->n_mixture > CNF_GU_MAX_MIXTURE)
+        return fail("%s: n_mixture must be 1..%d (got %d)", who, CNF_GU_MAX_MIXTURE, gu->n_mixture);
+    for (int c = 0; c < gu->n_mixture; ++c)
+        if (!(gu->sigma[c] > 0.f) || !(gu->unif_intsect[c] >= 0.f) || !(gu->unif_p[c] >= 0.f && gu->unif_p[c] <= 1.f) ||
+            !std::isfinite(gu->mean[c]))
+            return fail("%s: component %d: need sigma > 0, unif_intsect >= 0, 0 <= unif_p <= 1, finite mean", who, c);
+    return 0;
+}
+
+int cnf_gu_sample_rows(const CnfGuDesc* gu, uint64_t seed, uint32_t call, int64_t row0, int64_t rows, float* out, void* stream) {
+    if (!gu || !out) return fail("cnf_gu_sample_rows: NULL pointer");
+    if (rows <= 0 || row0 < 0) return fail("cnf_gu_sample_rows: need rows > 0 and row0 >= 0 (got %ld, %ld)", (long)rows, (long)row0);
+    if (check_gu("cnf_gu_sample_rows", gu)) return 1;
+    hipError_t err = cnf::launch_gu_sample_rows(*gu, seed, call, row0, rows, out, (hipStream_t)stream);
+    if (err != hipSuccess) return fail("cnf_gu_sample_rows: launch failed: %s", hipGetErrorString(err));
     return 0;
 }
 

@@ -1,5 +1,8 @@
 // cnf_launch.h -- kernel argument block and launcher prototypes shared by the .hip translation units.
 #pragma once
+#include <atomic>
+#include <mutex>
+
 #include "cnf_device.h"
 
 namespace cnf {
@@ -52,22 +55,37 @@ hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s);   // + grad_z1
 // with foreign work still ends in CNF_ERR_SYNC_TIMEOUT (bounded spin), not in a hang.
 template <class K>
 inline hipError_t check_resident(K kernel, int threads, int grid) {
+    // one table per kernel SIGNATURE (K is the function-pointer type): every kernel x device of that signature shares it.
+    // Entries are written under the mutex and published by the release store of the count; readers scan the published
+    // prefix without the lock (launch path, also under stream capture).
     struct Entry { const void* fn; int dev; int capacity; };
-    static Entry cache[64];
-    static int n_cached = 0;
+    constexpr int kSlots = 512;
+    static Entry cache[kSlots];
+    static std::atomic<int> n_cached{0};
+    static std::mutex mu;
     if (grid <= 1) return hipSuccess;
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
     if (err != hipSuccess) return err;
     const void* fn = reinterpret_cast<const void*>(kernel);
-    for (int i = 0; i < n_cached; ++i)
+    const int n = n_cached.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
         if (cache[i].fn == fn && cache[i].dev == dev) return grid <= cache[i].capacity ? hipSuccess : hipErrorCooperativeLaunchTooLarge;
     int per_cu = 0, cus = 0;
     err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0);
     if (err == hipSuccess) err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (err != hipSuccess) return err;
     const int capacity = per_cu * cus;
-    if (n_cached < 64) cache[n_cached++] = Entry{fn, dev, capacity};   // benign race: two threads may both fill an entry
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const int m = n_cached.load(std::memory_order_relaxed);
+        bool have = false;
+        for (int i = 0; i < m; ++i) have |= cache[i].fn == fn && cache[i].dev == dev;
+        if (!have && m < kSlots) {
+            cache[m] = Entry{fn, dev, capacity};
+            n_cached.store(m + 1, std::memory_order_release);
+        }
+    }
     return grid <= capacity ? hipSuccess : hipErrorCooperativeLaunchTooLarge;
 }
 

@@ -1219,12 +1219,12 @@ hipError_t launch_split16_fixed_bwd(const SolveArgs& a, hipStream_t s) {
 
 hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
-    dbg_timing_begin(s);
     {
         const hipError_t res = a.spread ? check_resident(dopri5_bwd_split16_kernel<true>, kThreads, 2 * grid)
                                         : check_resident(dopri5_bwd_split16_kernel<false>, kThreads, grid);
         if (res != hipSuccess) return res;
     }
+    dbg_timing_begin(s);
     if (a.spread) hipLaunchKernelGGL(dopri5_bwd_split16_kernel<true>, dim3(2 * grid), dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL(dopri5_bwd_split16_kernel<false>, dim3(grid), dim3(kThreads), 0, s, a);
     dbg_timing_end(s);
@@ -1237,11 +1237,11 @@ hipError_t launch_split16_bwd(const SolveArgs& a, hipStream_t s) {
 
 hipError_t launch_split16_fwd(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
-    dbg_timing_begin(s);
     {
         const hipError_t res = check_resident(dopri5_split16_kernel, kThreads, grid);
         if (res != hipSuccess) return res;
     }
+    dbg_timing_begin(s);
     hipLaunchKernelGGL(dopri5_split16_kernel, dim3(grid), dim3(kThreads), 0, s, a);
     dbg_timing_end(s);
     return hipGetLastError();

@@ -983,11 +983,11 @@ static hipError_t wide_bwd_t(const SolveArgs& a0, float* ws_floats, hipStream_t 
     hipError_t err = wide_prep(D, a.params, wt, s);
     if (err != hipSuccess) return err;
     const int grid = (int)((a.rows + kRows - 1) / kRows);
-    dbg_timing_begin(s);
     {
         const hipError_t res = check_resident(wide_bwd_kernel<D, HUTCH>, kThreads, a.spread ? 2 * grid : grid);
         if (res != hipSuccess) return res;
     }
+    dbg_timing_begin(s);
     hipLaunchKernelGGL((wide_bwd_kernel<D, HUTCH>), dim3(a.spread ? 2 * grid : grid), dim3(kThreads), 0, s, a, (const float*)wt);
     dbg_timing_end(s);
     err = hipGetLastError();

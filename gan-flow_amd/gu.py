@@ -86,6 +86,31 @@ class DeviceSampler:
     def get_sample(self, size):
         return self.fill(torch.empty(size, self.cols, dtype=torch.float32, device=self.device))
 
+    def get_rows(self, lo, hi, call=0):
+        """Rows lo .. hi-1 of draw number `call`, addressed by GLOBAL row index (cnf_gu_sample_rows): stateless, so the
+        shards of a data set hold the same values for every number of shards (sharded evaluation, BASELINE config 3)."""
+        out = torch.empty(max(0, hi - lo), self.cols, dtype=torch.float32, device=self.device)
+        return self._native.gu_sample_rows(self.desc, self.seed, call, lo, out)
+
+
+class DeviceNormalRows:
+    """N(mean, sigma^2) rows of `cols` in {1, 2} columns by global row index, from the same counter-based generator
+    (a one-component mixture without a uniform part; with two columns the second is U(0, 1), the data sets' nuisance
+    column, so use cols = 1 per coordinate and stack for a d-dimensional normal)."""
+
+    def __init__(self, device, seed, mean=0.0, sigma=1.0):
+        from . import _native
+        self._native = _native
+        self.device = torch.device(device)
+        self.seed = int(seed)
+        self.desc = _native.gu_desc([mean], [sigma], [0.0], [0.0], False)
+
+    def get_rows(self, lo, hi, dim=1, call=0):
+        cols = [self._native.gu_sample_rows(self.desc, self.seed, call * 16 + c, lo,
+                                            torch.empty(max(0, hi - lo), 1, dtype=torch.float32, device=self.device))
+                for c in range(dim)]
+        return cols[0] if dim == 1 else torch.cat(cols, 1)
+
 
 def make_gu(gu_num, device="cpu", seed=1, extend_dim=True):
     """The two data sets of the study (/root/reference/model_plot.py:36-55, gu.py:105-116)."""

@@ -62,6 +62,25 @@ def count_nfe(model):
     return sum(block.num_evals() for block in model.chain if hasattr(block, "num_evals"))
 
 
+class checked_solves:
+    """Within the block every CNF block reads its solver status back after each solve and raises on failure (sync_stats),
+    whatever a captured training step had set: evaluation must never turn a failed solve (NaN, max steps, sync timeout)
+    into a logged number."""
+
+    def __init__(self, model):
+        self.blocks = [b for b in model.chain if hasattr(b, "sync_stats")]
+
+    def __enter__(self):
+        self.saved = [b.sync_stats for b in self.blocks]
+        for b in self.blocks:
+            b.sync_stats = True
+
+    def __exit__(self, *exc):
+        for b, v in zip(self.blocks, self.saved):
+            b.sync_stats = v
+        return False
+
+
 def evaluate_w_distance(model, data, eval_size=100000, chunk=10000, device=None):
     """The reference's sampling protocol (model_plot.py:93-101): eval_size prior draws pushed through sample_fn in
     10 000-row chunks, 1-D Wasserstein distance of the first coordinate against fresh data.  `data`: anything with
@@ -71,7 +90,7 @@ def evaluate_w_distance(model, data, eval_size=100000, chunk=10000, device=None)
     was_training = model.training
     model.eval()
     sample_fn, _ = get_transforms(model)
-    with torch.no_grad():
+    with torch.no_grad(), checked_solves(model):
         z = torch.randn(eval_size, dim, device=device)
         fake = torch.cat([sample_fn(zc) for zc in torch.split(z, chunk)], 0)
         real = data.get_sample(eval_size).to(device)
@@ -512,14 +531,18 @@ def main(argv=None):
         ck = torch.load(args.resume, map_location=device, weights_only=True)
         model.load_state_dict(ck["model"])
         start_itr = int(ck["itr"])
+        # a fresh sample stream for the rest of the run -- BEFORE the fused step is rebuilt: the captured graph holds the
+        # sampler's seed as a by-value kernel argument, so a seed changed afterwards would never reach training (the resumed
+        # run would replay the batches the original run had already trained on)
+        data = make_gu(args.gu_num, device="cpu", seed=args.seed + start_itr, extend_dim=True)
+        if on_device is not None:
+            on_device = data.device_sampler(device)
+            train_sampler = on_device if args.fused else None
         if fused is not None:
             fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay, sampler=train_sampler)   # parameters were re-assigned: re-alias
             fused.load_state_dict(ck["optimizer"])
         else:
             optimizer.load_state_dict(ck["optimizer"])
-        data = make_gu(args.gu_num, device="cpu", seed=args.seed + start_itr, extend_dim=True)   # a fresh sample stream
-        if on_device is not None:
-            on_device.seed = args.seed + start_itr
         logger.info("resumed from %s at iteration %d" % (args.resume, start_itr))
 
     def checkpoint(itr):
@@ -534,7 +557,7 @@ def main(argv=None):
         model.eval()
         for b in model.chain:
             b.tile_rows = 16          # evaluation: every 16-row tile controls its own step
-        with torch.no_grad():
+        with torch.no_grad(), checked_solves(model):
             lp = model_log_prob(model, (on_device or data).get_sample(args.eval_logp_size).to(device)).mean().item()
         for b in model.chain:
             b.tile_rows = 0

@@ -249,6 +249,14 @@ typedef struct CnfGuDesc {
 } CnfGuDesc;
 int cnf_gu_sample(const CnfGuDesc *gu, uint64_t seed, int32_t *state, int64_t rows, float *out, void *stream);
 
+/* The same generator addressed by GLOBAL row index, stateless: rows row0 .. row0 + rows - 1 of draw number `call` (the
+ * Philox counter is (row, call), exactly cnf_gu_sample's; cnf_gu_sample_rows(gu, seed, c, 0, n, ..) writes what the c-th
+ * cnf_gu_sample call of n rows writes).  For sharded evaluation (BASELINE config 3): a rank draws ITS
+ * rows of a data set of any size, and the set is the same for every number of ranks.  The reference has no counterpart:
+ * its evaluation data are one host array (/root/reference/model_plot.py:93-101).  With n_mixture = 1, unif_p = 0 the rows
+ * are N(mean, sigma^2): the prior draws of the sampling protocol and the Gaussian "tail" half of config 3's points.   */
+int cnf_gu_sample_rows(const CnfGuDesc *gu, uint64_t seed, uint32_t call, int64_t row0, int64_t rows, float *out, void *stream);
+
 /* Diagnostics (no counterpart in the reference): fill the LDS of every compute unit with `pattern`.  LDS keeps the
  * previous kernel's content, so the tests poison it (NaN bit patterns) before a solve to prove that no result
  * depends on it.  scratch_word: one uint32 of device memory (never written in practice).                    */

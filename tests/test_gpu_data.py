@@ -147,3 +147,71 @@ def test_config1_unimodal_training_matches_the_oracle():
     po = torch.cat([p.detach().reshape(-1) for p in mo.chain[0].odefunc.odefunc.diffeq.parameters()])
     pp = torch.cat([p.detach().reshape(-1) for p in mp.chain[0].odefunc.odefunc.diffeq.parameters()]).cpu()
     assert (po - pp).abs().max().item() < 5e-5            # five Adam steps of 1e-3 each moved the weights by ~5e-3
+
+
+@pytest.mark.gpu
+def test_rows_by_global_index_do_not_depend_on_the_sharding():
+    """cnf_gu_sample_rows (include/cnf_hip.h): the generator addressed by GLOBAL row index.  Shards of a data set hold the bits
+    of the unsharded draw for every split (config 3 evaluates the same 2^24 rows at 1, 2, 4 and 8 GPUs); call c of n rows
+    equals the c-th cnf_gu_sample call; the one-component form is a normal sample; and the sharded mean log-likelihood of
+    the same rows, evaluated as one shard or as two, agrees to 1e-6 relative (tile-local step control is per 16-row tile
+    and the shards here are tile-aligned, so only the summation order differs)."""
+    import numpy as np
+    from gan_flow_amd import gu_ffjord, parallel_eval
+    from gan_flow_amd.gu import DeviceNormalRows, make_gu
+    n = 100003
+    for gu_num, ext in ((8, True), (1, False)):
+        smp = make_gu(gu_num, device="cpu", seed=11, extend_dim=ext).device_sampler(DEV)
+        full = smp.get_rows(0, n, call=3)
+        for world in (2, 3, 8):
+            parts = [smp.get_rows(*parallel_eval.shard_bounds(n, r, world), call=3) for r in range(world)]
+            assert torch.equal(torch.cat(parts), full)
+        first, second = smp.get_sample(4096), smp.get_sample(4096)          # the stateful entry point: calls 0 and 1
+        assert torch.equal(first, smp.get_rows(0, 4096, call=0)) and torch.equal(second, smp.get_rows(0, 4096, call=1))
+        assert smp.get_rows(5, 5).shape[0] == 0
+    z = DeviceNormalRows(DEV, seed=7).get_rows(0, 400000, dim=2)
+    assert z.shape == (400000, 2) and abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1.0) < 5e-3
+    assert abs(torch.corrcoef(z.T)[0, 1].item()) < 5e-3
+    t = DeviceNormalRows(DEV, seed=7, mean=45.0, sigma=23.0).get_rows(1000, 201000)
+    assert abs(t.mean().item() - 45.0) < 0.2 and abs(t.std().item() - 23.0) < 0.2
+    # one shard vs two shards of the same rows through the trained d = 1 model
+    a = np.load(os.path.join(GOLDEN, "ffjord_multimodal.npz"))
+    em = gu_ffjord.build_model(1)
+    em.load_state_dict({k: torch.from_numpy(a[k]) for k in a.files})
+    em = em.to(DEV).eval()
+    for b in em.chain:
+        b.tile_rows = 16
+    mix = make_gu(8, device="cpu", seed=1234, extend_dim=False).device_sampler(DEV)
+    rows = 1 << 14
+    with torch.no_grad():
+        lp = lambda v: parallel_eval.model_log_prob(em, v)
+        one, n1 = parallel_eval.sharded_mean_log_likelihood(lp, mix.get_rows(0, rows))
+        halves = [lp(mix.get_rows(lo, hi)).double().sum().item() for lo, hi in ((0, rows // 2), (rows // 2, rows))]
+    assert n1 == rows and abs(sum(halves) / rows - one) <= 1e-6 * abs(one)
+
+
+@pytest.mark.gpu
+def test_resumed_run_trains_on_fresh_batches(tmp_path, monkeypatch):
+    """`gu_maf --resume` with the default device sampler: the captured graph holds the sampler's seed by value, so the resume
+    path must move the seed BEFORE it rebuilds the fused step -- else the resumed run replays the batches the original run
+    had already trained on.  The batches a run trains on are recorded off FusedTrainStep's static input."""
+    from gan_flow_amd import gu_ffjord
+    seen = []
+    orig = gu_ffjord.FusedTrainStep.__call__
+
+    def recording(self, x=None):
+        out = orig(self, x)
+        seen.append(self.static_x[:8].clone())
+        return out
+
+    monkeypatch.setattr(gu_ffjord.FusedTrainStep, "__call__", recording)
+    common = ["--gu_num", "8", "--batch_size", "512", "--log_interval", "1000", "--eval_size", "2000", "--eval_logp_size", "512",
+              "--save", str(tmp_path)]
+    gu_ffjord.main(common + ["--niters", "3"])
+    first = [t.cpu() for t in seen]
+    del seen[:]
+    gu_ffjord.main(common + ["--niters", "6", "--resume", str(tmp_path / "ffjord_checkpoint.pth")])
+    resumed = [t.cpu() for t in seen]
+    assert len(first) == 3 and len(resumed) == 3
+    assert all(not torch.equal(a, b) for a in first for b in resumed)
+    assert all(not torch.equal(resumed[i], resumed[j]) for i in range(3) for j in range(i))

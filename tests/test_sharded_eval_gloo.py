@@ -74,3 +74,54 @@ def test_shard_bounds_cover_and_balance():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _rows_by_global_index(lo, hi, seed):
+    """A stand-in for gu.DeviceSampler.get_rows / DeviceNormalRows.get_rows (HIP kernels): values that are a function of the
+    GLOBAL row index alone."""
+    idx = torch.arange(lo, hi, dtype=torch.float64)
+    return ((torch.sin(idx * 12.9898 + seed) * 43758.5453) % 1.0).float().reshape(-1, 1)
+
+
+def _worker_wd(rank, world, port, n_real, n_fake, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gan_flow_amd import parallel_eval
+    lo_r, hi_r = parallel_eval.shard_bounds(n_real, rank, world)
+    real = _rows_by_global_index(lo_r, hi_r, 1.0) * 3.0 + 4.0
+    fake = parallel_eval.sharded_sample(lambda z: z * 2.5 + 4.5, n_fake, 1, rank, world, "cpu",
+                                        prior_rows=lambda a, b: _rows_by_global_index(a, b, 2.0))
+    wd = parallel_eval.sharded_w_distance(real, fake, n_real, n_fake)
+    mean, rows = parallel_eval.sharded_mean_log_likelihood(lambda x: -x * x, real)
+    q.put((rank, wd, mean, rows))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_real,n_fake", [(1001, 1001), (1000, 777)])
+def test_sharded_w_distance_and_world_size_invariance(n_real, n_fake):
+    """The sampling half of BASELINE config 3 at N > 1: the study's metric (scipy's 1-D Wasserstein distance rounded to 4
+    decimals, /root/reference/util.py:16-20) over ALL ranks' samples, from shards drawn by global row index -- the same
+    number on every rank, equal to the single-process value on the unsharded arrays, and the sharded mean log-likelihood
+    equal to the N = 1 value to 1e-6 relative (summation order only)."""
+    from scipy.stats import wasserstein_distance
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_wd, args=(r, world, port, n_real, n_fake, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    real = _rows_by_global_index(0, n_real, 1.0) * 3.0 + 4.0
+    fake = _rows_by_global_index(0, n_fake, 2.0) * 2.5 + 4.5
+    want = round(float(wasserstein_distance(real.reshape(-1).numpy(), fake.reshape(-1).numpy())), 4)
+    assert res[0][1] == res[1][1] and abs(res[0][1] - want) <= 1e-4
+    from gan_flow_amd import parallel_eval
+    one_wd = parallel_eval.sharded_w_distance(real, fake, n_real, n_fake)           # no process group: N = 1
+    one_mean, one_rows = parallel_eval.sharded_mean_log_likelihood(lambda x: -x * x, real)
+    assert one_wd == res[0][1]
+    assert res[0][3] == one_rows == n_real and abs(res[0][2] - one_mean) <= 1e-6 * abs(one_mean)
