@@ -217,6 +217,7 @@ class Stats:
 
 FLAG_CLEAN = 1   # CNF_FLAG_CLEAN, include/cnf_hip.h
 FLAG_SPREAD = 2  # CNF_FLAG_SPREAD
+FLAG_FWD_FOUR_WAVES = 8  # CNF_FLAG_FWD_FOUR_WAVES: diagnostics, the four-wave forward kernel (same bits)
 FLAG_ADJ_CONTROL_ALL = 4  # CNF_FLAG_ADJ_CONTROL_ALL: a_z and a_logp under the adjoint solve's step control as well
 
 

@@ -240,8 +240,9 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
     a.residual = is_residual(net) ? 1 : 0;
     a.step_size = 0.f;
     a.after = opts->after;
+    a.fwd4 = (opts->flags & CNF_FLAG_FWD_FOUR_WAVES) ? 1 : 0;
     if (opts->after == stats) return fail("%s: opts->after must be another block than this solve's stats", who);
-    if (opts->flags & ~(CNF_FLAG_CLEAN | CNF_FLAG_SPREAD | CNF_FLAG_ADJ_CONTROL_ALL)) return fail("%s: unknown bits in opts->flags (0x%x)", who, (unsigned)opts->flags);
+    if (opts->flags & ~(CNF_FLAG_CLEAN | CNF_FLAG_SPREAD | CNF_FLAG_ADJ_CONTROL_ALL | CNF_FLAG_FWD_FOUR_WAVES)) return fail("%s: unknown bits in opts->flags (0x%x)", who, (unsigned)opts->flags);
     global = true;
     if (opts->solver == CNF_SOLVER_DOPRI5) {
         if (!(opts->rtol > 0.f) || !(opts->atol > 0.f)) return fail("%s: dopri5 needs rtol > 0 and atol > 0", who);

@@ -37,6 +37,7 @@ struct SolveArgs {
     int residual;         // CNF_DIV_RESIDUAL: the dynamics are f(z) - z (ODEfunc(residual=True))
     int keep_slabs;       // adjoint: leave the per-workgroup gradient slabs for launch_adam_slabs (no reduction kernel)
     int adj_all;          // adjoint, CNF_FLAG_ADJ_CONTROL_ALL: a_z and a_logp under step control as well (cnf_device.h)
+    int fwd4;             // CNF_FLAG_FWD_FOUR_WAVES: the four-wave forward kernel where the eight-wave one would run
     const CnfStats* after;  // CnfSolverOpts.after (nullable): exit at once with that block's status when it is non-zero
 };
 

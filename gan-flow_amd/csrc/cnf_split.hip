@@ -1793,9 +1793,31 @@ hipError_t launch_adam_slabs(const float* slab, int ntiles, int P, int split_at,
 
 #endif   // CNF_SPLIT_PART == 2
 #if CNF_SPLIT_PART == 1
+}  // namespace cnf
+#include "cnf_split_fwd_tw.h"
+namespace cnf {
+
+// eight waves per workgroup (kFwdTwNote, cnf_split_fwd_tw.h) wherever the tangent streams are a separable share of the
+// work: d <= 2.  CNF_FLAG_FWD_FOUR_WAVES keeps the four-wave kernel (same bits).
+#ifdef CNF_NO_FWD_HELPER_WAVES
+constexpr bool kFwdHelperWaves = false;
+#else
+constexpr bool kFwdHelperWaves = true;
+#endif
+
 template <int D, bool HUTCH>
 static hipError_t split_fwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
+    if constexpr (D <= 2) {
+        if (kFwdHelperWaves && !a.fwd4) {
+            hipError_t res = check_resident(dopri5_split_tw_kernel<D, HUTCH>, 2 * kThreads, grid);
+            if (res != hipSuccess) return res;
+            dbg_timing_begin(s);
+            hipLaunchKernelGGL((dopri5_split_tw_kernel<D, HUTCH>), dim3(grid), dim3(2 * kThreads), 0, s, a);
+            dbg_timing_end(s);
+            return hipGetLastError();
+        }
+    }
     hipError_t res = check_resident(dopri5_split_kernel<D, HUTCH>, kThreads, grid);
     if (res != hipSuccess) return res;
     dbg_timing_begin(s);

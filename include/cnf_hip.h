@@ -82,7 +82,13 @@ typedef struct CnfSolverOpts {
  * it timed out).  The call then enqueues no memset at all: tight loops and captured graphs save four fill nodes
  * per training iteration.  stats->status becomes sticky (it is only ever raised).  Ignored (memsets kept) where it
  * does not apply: rk4, tile-local control, more than 4096 rows.                                            */
-enum { CNF_FLAG_CLEAN = 1, CNF_FLAG_SPREAD = 2, CNF_FLAG_ADJ_CONTROL_ALL = 4 };
+enum { CNF_FLAG_CLEAN = 1, CNF_FLAG_SPREAD = 2, CNF_FLAG_ADJ_CONTROL_ALL = 4, CNF_FLAG_FWD_FOUR_WAVES = 8 };
+
+/* CNF_FLAG_FWD_FOUR_WAVES (cnf_solve_fwd, cnf_solve_fwd_static; diagnostics): run a batch-global dopri5 forward solve of
+ * hidden width 64, dim <= 2, at most 4096 rows on the four-wave kernel (every wave carries the value and the tangent
+ * streams of its feature tile) instead of the eight-wave one (value stream on four waves, tangent streams and log p on the
+ * second wave of each SIMD, one barrier interval behind).  Same arithmetic, identical bits; for A/B timing and the test
+ * that holds the two kernels to each other.  Ignored where the eight-wave kernel does not apply.                        */
 
 /* CNF_FLAG_SPREAD (cnf_solve_bwd, at most half as many 16-row tiles as the device has
  * compute units -- 2048 rows on an MI355X; ignored otherwise): the adjoint runs TWO workgroups per tile.  Both

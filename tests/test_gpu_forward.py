@@ -532,3 +532,52 @@ def test_captured_unflagged_solve_survives_eager_solves_between_replays():
             torch.sort(torch.randn(100000, device=DEV))
             torch.zeros(1 << 20, device=DEV)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", ["rand_d2", "rand_d2_ragged", "rand_d1_4096", "rand_d2_hutch", "rand_d2_residual", "rand_d2_reverse_logp0",
+                                  "stiff_d1", "stiff_d1_reverse", "stiff_d2", "tiny"])
+def test_eight_wave_forward_solve_equals_four_wave(case):
+    """The batch-global forward solve runs eight waves per workgroup (csrc/cnf_split_fwd_tw.h, kFwdTwNote): the value stream on
+    four waves, the tangent streams, the divergence and everything of log p on the second wave of each SIMD, one barrier
+    interval behind.  Same arithmetic operation for operation as the four-wave kernel (CNF_FLAG_FWD_FOUR_WAVES): identical
+    bits in z and log p and an identical step sequence -- on random and trained (stiff: hundreds of attempts, rejections)
+    fields, ragged last tiles, both time directions, Hutchinson, residual dynamics, a given log p0, and through
+    cnf_solve_fwd_static."""
+    nat = _native()
+    g = torch.Generator().manual_seed(41)
+    dim = 1 if "d1" in case else 2
+    hutch = "hutch" in case
+    rows = {"rand_d2": 2048, "rand_d2_ragged": 203, "rand_d1_4096": 4096, "rand_d2_hutch": 500, "rand_d2_residual": 777,
+            "rand_d2_reverse_logp0": 1000, "stiff_d1": 1024, "stiff_d1_reverse": 640, "stiff_d2": 384, "tiny": 3}[case]
+    if case.startswith("stiff_d1"):
+        m = oracle_fixture_model("multimodal")
+        x = (torch.randn(rows, 1, generator=g) if "reverse" in case else torch.rand(rows, 1, generator=g) * 90.0 - 5.0)
+    elif case == "stiff_d2":
+        from _helpers import embed_trained_multimodal
+        m = oracle.build_cnf(2)
+        embed_trained_multimodal(m)
+        x = torch.cat([torch.rand(rows, 1, generator=g) * 90.0 - 5.0, torch.rand(rows, 1, generator=g)], 1)
+    else:
+        m = oracle_random_model(dim, seed=17, divergence_fn="approximate" if hutch else "brute_force", scale=2.0)
+        x = torch.randn(rows, dim, generator=g) * 1.5
+    net = nat.net_desc(dim, 64, 3, hutch, residual="residual" in case)
+    params = _flat(m).to(DEV)
+    x = x.to(DEV)
+    e = torch.randn(rows, dim, generator=g).to(DEV) if hutch else None
+    lp0 = torch.randn(rows, 1, generator=g).to(DEV) if "logp0" in case else None
+    t0, t1 = (0.5, 0.0) if "reverse" in case else (0.0, 0.5)
+    out = {}
+    for name, flags in (("eight", 0), ("four", nat.FLAG_FWD_FOUR_WAVES)):
+        z, lp, st = nat.solve_fwd(net, params, x, lp0, t0, t1, nat.make_opts("dopri5", 1e-5, 1e-5, flags=flags), e)
+        torch.cuda.synchronize()
+        st = nat.Stats(st)
+        st.raise_for_status()
+        out[name] = (z.clone(), lp.clone(), (st.nfe, st.n_accepted, st.n_rejected, st.evals_run, st.last_dt))
+    zs, lps, sts = nat.solve_fwd_static(net, params, x, lp0, t0, t1, nat.make_opts("dopri5", 1e-5, 1e-5), e)
+    torch.cuda.synchronize()
+    assert out["eight"][2] == out["four"][2], (out["eight"][2], out["four"][2])
+    assert torch.equal(out["eight"][0], out["four"][0]) and torch.equal(out["eight"][1], out["four"][1])
+    assert torch.equal(zs, out["four"][0]) and torch.equal(lps, out["four"][1])
+    if case.startswith("stiff"):
+        assert out["eight"][2][1] > 100 and out["eight"][2][2] > 5
+    assert torch.isfinite(out["eight"][0]).all() and out["eight"][1].abs().max().item() > 0

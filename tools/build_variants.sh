@@ -11,6 +11,7 @@ SRC=${SRC:-cnf_split}
 case $SRC in cnf_fwd|cnf_wide_bwd) FLAGS="$FLAGS -Xclang -target-feature -Xclang -packed-fp32-ops";; esac
 # the files the Makefile compiles with the max-ILP scheduler (ILP_FLAGS there)
 case $SRC in cnf_split_fwd) FLAGS="$FLAGS -mllvm -amdgpu-sched-strategy=max-ilp";; esac
+# cnf_split goes through the hazard pass in the Makefile; a variant of it built here does NOT (timing experiments only)
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   /opt/rocm/bin/hipcc $FLAGS $defs -c $SRC.hip -o ../variants/${SRC}_$name.o
