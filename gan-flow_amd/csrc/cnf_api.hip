@@ -108,7 +108,7 @@ int check_net(const CnfNetDesc* n) {
     if (!n) return fail("net is NULL");
     if (!supported(n))
         return fail("unsupported net: dim=%d hidden=%d n_hidden=%d divergence=%d (built: hidden 64 x 3 with dim 1|2 exact, "
-                    "dim 2|16 Hutchinson; hidden 256 x 3 with dim 1|2 exact, dim 2 Hutchinson, forward path only)",
+                    "dim 2|16 Hutchinson; hidden 256 x 3 with dim 1|2 exact, dim 2 Hutchinson)",
                     n->dim, n->hidden, n->n_hidden, n->divergence);
     return 0;
 }

@@ -10,8 +10,8 @@
 // from the parameter vector (L2-resident, identical for all workgroups) into registers with one
 // global_load_dwordx4 per block, software-prefetched one input tile ahead.  Per CU that is 256 KB per layer
 // against ~25k cycles of MFMA work per wave, i.e. ~10 B/clk of L2 bandwidth: the layer is MFMA-bound.
-// Forward path only (field evaluation, dopri5 with batch-global or tile-local control, rk4); the adjoint at this
-// width needs 2 x 256 x 256 gradient accumulators per workgroup, which do not fit in registers: not built yet.
+// This file is the forward path (field evaluation, dopri5 with batch-global or tile-local control, rk4 / euler / midpoint);
+// the adjoint at this width is cnf_wide_bwd.hip (its 2 x 256 x 256 gradient sums per workgroup live in workspace slots).
 #include <type_traits>
 
 #include "cnf_wide.h"
