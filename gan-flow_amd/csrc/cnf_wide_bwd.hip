@@ -443,10 +443,74 @@ __device__ __forceinline__ void aug_eval_wide(const WideNetLds<D>& n, WS& ws, Wi
     }
 }
 
+}  // namespace cnf
+#include "cnf_wide_bwd_b16.h"
+namespace cnf {
+
+// The 256 x 256 products of the adjoint on the bf16 matrix pipe (cnf_wide_bwd_b16.h); 0 rebuilds the fp32-MFMA evaluation
+// above (tools/build_variants.sh, A/B timing).
+#ifndef CNF_WIDE_BWD_BF16
+#define CNF_WIDE_BWD_BF16 1
+#endif
+constexpr bool kWideBwdB16 = CNF_WIDE_BWD_BF16 != 0;
+// head of the adjoint's workspace, in floats: W^T of the two matrices in fp32, or the pieces of W and W^T
+constexpr size_t kWideBwdHeadFloats = kWideBwdB16 ? 2 * kWideSetBytes / sizeof(float) : (size_t)2 * kWH * kWH;
+
+// Shared memory of the adjoint kernels, by evaluation.  bf16: the two piece buffers take 144 KB at three streams, so the
+// slopes are ONE array for the four waves.  Every wave carries an identical copy of the Runge-Kutta state and computes
+// identical slopes (f, div and vz come out of LDS sums read in one order), so all four store the SAME value to a slot, each
+// reads a slot only after its own store to it or under a zero weight, and a slot is rewritten for the next step only behind
+// the barriers of the step's grid reduction and commit: no wave can observe a value that differs from its own.
+template <int D, int NS, int C, bool B16>
+struct WideBwdShared;
+template <int D, int NS, int C>
+struct WideBwdShared<D, NS, C, false> {
+    static constexpr bool kB16 = false;
+    WideNetLds<D> net;
+    WideWaveLds<C> wl[kNW];
+    WideXchg<D, NS> xc;
+    float part2[kNW][D][kRows];
+    __device__ __forceinline__ float (&kst(int w))[7][C][kRows] { return wl[w].kst; }
+    __device__ __forceinline__ void stage(const float* __restrict__ p, int tid) { wide_stage_net(net, p, tid); }
+    __device__ __forceinline__ void zero(int tid) { zero_slopes(wl, kNW, tid); }
+    __device__ __forceinline__ void* fold_area() { return nullptr; }
+};
+template <int D, int NS, int C>
+struct WideBwdShared<D, NS, C, true> {
+    static constexpr bool kB16 = true;
+    WideBwdLds<D, NS> x;
+    float kst1[7][C][kRows];
+    __device__ __forceinline__ float (&kst(int))[7][C][kRows] { return kst1; }
+    __device__ __forceinline__ void stage(const float* __restrict__ p, int tid) { wide_bwd_stage(x, p, tid); }
+    __device__ __forceinline__ void zero(int tid) {
+        for (int idx = tid; idx < 7 * C * kRows; idx += kThreads) (&kst1[0][0][0])[idx] = 0.f;   // zero_slopes: 0 x stale NaN
+    }
+    // an accepted step's fold stages its factors where the evaluations exchange theirs (wide_fold_factors)
+    __device__ __forceinline__ void* fold_area() {
+        static_assert(sizeof(WideFoldLds<NS>) <= sizeof(x.xb16), "the fold's piece area fits in the exchange buffers");
+        return &x.xb16[0][0][0][0][0][0];
+    }
+};
+// wmat: the workspace head (fp32: transposed matrices; bf16: wide_bwd_pieces_kernel's output)
+template <int D, bool HUTCH, bool FACT, class SH>
+__device__ __forceinline__ void aug_eval_sh(SH& sh, const float* __restrict__ params, const float* __restrict__ wmat, int lane,
+                                            int wave, float t, const float (&z)[D], const float (&e)[D], const float (&az)[D],
+                                            float al, float w, bool with_theta, float (&f)[D], float& div, float (&vz)[D],
+                                            float* __restrict__ slot, int part = 0) {
+    constexpr int NS = (HUTCH ? 1 : D) + 1;
+    if constexpr (SH::kB16)
+        aug_eval_wide_b16<D, HUTCH, NS, FACT>(sh.x, params, reinterpret_cast<const u32x4*>(wmat), lane, wave, t, z, e, az, al, w, with_theta,
+                                        f, div, vz, slot, part);
+    else
+        aug_eval_wide<D, HUTCH>(sh.net, sh.wl[wave], sh.xc, sh.part2, params, wmat, lane, wave, t, z, e, az, al, w, with_theta, f,
+                                div, vz, slot, part);
+}
+
 // fold the stage slots of an accepted step into the workgroup's running total: total (+)= sum_s wts[s] * slot[sl[s]]
-template <int D>
+// FACT (NS = streams): the stage slots hold the matrices' sums as factors (cnf_wide_bwd_b16.h): their share is formed here
+template <int D, int NS = 0, bool FACT = false>
 __device__ inline void wide_commit(float* __restrict__ region, const int (&sl)[7], const float (&wts)[7], bool first, int tid,
-                                   int part = 0) {
+                                   int part = 0, void* fold_lds = nullptr) {
     constexpr int SF = kWideSlotF<D>;
     // the slots are written and folded by waves of this one workgroup (one compute unit, one vector L1): workgroup scope
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -460,7 +524,19 @@ __device__ inline void wide_commit(float* __restrict__ region, const int (&sl)[7
     static_assert(WideSmallIdx<D>::v3 % 4 == 0 && kWideBig % 8 == 0, "16-byte ranges");
     const int lo4[2] = {part == 1 ? kBig4 / 2 : 0, part == 1 ? kV34 : kBig4};
     const int hi4[2] = {part == 2 ? kBig4 / 2 : kBig4, part == 2 ? kV34 : SF / 4};
-    for (int rg = 0; rg < 2; ++rg) {
+    if constexpr (FACT) {
+        static_assert(2 * kWideFactLayer<(NS > 0 ? NS : 1)> <= kWideBig, "factors fit in a slot's matrix area");
+#ifndef CNF_EXP_WIDE_NO_COMMIT
+        for (int lc = 0; lc < 2; ++lc)
+            if (part == 0 || part == 2 - lc)   // part 1 keeps W3 (lc = 1), part 2 keeps W2 (lc = 0)
+                wide_fold_factors<NS>(*reinterpret_cast<WideFoldLds<(NS > 0 ? NS : 1)>*>(fold_lds), region, (size_t)SF, sl, wts, lc, first,
+                                      region + (size_t)kWideTotal * SF, tid);
+#endif
+    }
+    for (int rg = FACT ? 1 : 0; rg < 2; ++rg) {
+#ifdef CNF_EXP_WIDE_NO_COMMIT   // timing experiment: no fold of the stage slots
+        if (wts[0] < 1e30f) break;
+#endif
         const int end = hi4[rg];
         for (int base = lo4[rg] + tid; base < end; base += kThreads * U) {
             f32x4 acc[U];
@@ -499,12 +575,9 @@ __global__ __launch_bounds__(kThreads) void wide_aug_kernel(SolveArgs a, const f
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = 2 * D + 1;
-    __shared__ WideNetLds<D> net;
-    __shared__ WideWaveLds<C> wl[kNW];
-    __shared__ WideXchg<D, NS> xc;
-    __shared__ float part2[kNW][D][kRows];
+    __shared__ WideBwdShared<D, NS, C, kWideBwdB16> sh;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
-    wide_stage_net(net, a.params, tid);
+    sh.stage(a.params, tid);
     __syncthreads();
     const long row = (long)blockIdx.x * kRows + j;
     const bool valid = row < a.rows;
@@ -518,7 +591,7 @@ __global__ __launch_bounds__(kThreads) void wide_aug_kernel(SolveArgs a, const f
     }
     const float al = valid ? a_l[rr] : 0.f;
     float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
-    aug_eval_wide<D, HUTCH>(net, wl[w], xc, part2, a.params, wt, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, region);
+    aug_eval_sh<D, HUTCH, false>(sh, a.params, wt, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, region);
     #pragma unroll
     for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
         f[m] = fmaf(-res, zz[m], f[m]);
@@ -542,16 +615,13 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = 2 * D + 1;
     constexpr int CE = D + 1;
-    __shared__ WideNetLds<D> net;
-    __shared__ WideWaveLds<C> wl[kNW];
-    __shared__ WideXchg<D, NS> xc;
-    __shared__ float part2[kNW][D][kRows];
+    __shared__ WideBwdShared<D, NS, C, kWideBwdB16> sh;
     __shared__ RedLds red;
     __shared__ float wq[8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
-    wide_stage_net(net, a.params, tid);
-    zero_slopes(wl, kNW, tid);
+    sh.stage(a.params, tid);
+    sh.zero(tid);
     __syncthreads();
     // a.spread: two workgroups per tile, each keeping half of the d/dtheta sums (kSpreadNote, cnf_split.hip)
     const int tile = a.spread ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
@@ -560,7 +630,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
     const bool valid = row < a.rows;
     const bool counted = valid && lane < 16 && w == 0 && part != 2;
     const long rr = valid ? row : a.rows - 1;
-    WideWaveLds<C>& ws = wl[w];
+    float (&kst)[7][C][kRows] = sh.kst(w);
     float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
 
     GridSync gs{a.gran, (int)gridDim.x, 0u};
@@ -617,8 +687,8 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
         int lane_e = lane, lane_r = lane;
         if constexpr ((kWideRematLane & 1) != 0) asm volatile("" : "+v"(lane_e));
         if constexpr ((kWideRematLane & 4) != 0) asm volatile("" : "+v"(lane_r));
-        aug_eval_wide<D, HUTCH>(net, ws, xc, part2, a.params, wt, lane_e, w, sgn * ti, zz, ee, az, al, sgn, with_theta, f, div, vz,
-                                region + (size_t)slot_i * kWideSlotF<D>, part);
+        aug_eval_sh<D, HUTCH, kWideBwdB16>(sh, a.params, wt, lane_e, w, sgn * ti, zz, ee, az, al, sgn, with_theta, f, div, vz,
+                              region + (size_t)slot_i * kWideSlotF<D>, part);
         #pragma unroll
         for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
             f[m] = fmaf(-res, zz[m], f[m]);
@@ -637,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
             double S[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < CE; ++c) {
-                ws.kst[0][c][j] = k[c];
+                kst[0][c][j] = k[c];
                 sc[c] = atol + fabsf(y0[c]) * rtol;
                 const float u = y0[c] / sc[c], v = k[c] / sc[c];
                 if (counted) {
@@ -646,7 +716,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
                 }
             }
 #pragma unroll
-            for (int c = CE; c < C; ++c) ws.kst[0][c][j] = k[c];
+            for (int c = CE; c < C; ++c) kst[0][c][j] = k[c];
             if (!wg_allreduce4(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
             d1z = (float)sqrt(S[2] / nz);
@@ -674,14 +744,14 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
             double S[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < CE; ++c) {
-                const float u = (k[c] - ws.kst[0][c][j]) / sc[c];
+                const float u = (k[c] - kst[0][c][j]) / sc[c];
                 if (counted) S[c < D ? 0 : 1] += (double)u * u;
             }
             if (a.adj_all && counted) {
 #pragma unroll
                 for (int m = 0; m < D; ++m) {
                     const int c = D + 1 + m;
-                    const float u = (k[c] - ws.kst[0][c][j]) / (atol + fabsf(y0[c]) * rtol);
+                    const float u = (k[c] - kst[0][c][j]) / (atol + fabsf(y0[c]) * rtol);
                     S[3] += (double)u * u;
                 }
             }
@@ -692,7 +762,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
             restart = true;
         } else {
 #pragma unroll
-            for (int c = 0; c < C; ++c) ws.kst[stage][c][j] = k[c];
+            for (int c = 0; c < C; ++c) kst[stage][c][j] = k[c];
             if (stage < 6) {
                 ++stage;
             } else {
@@ -703,7 +773,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
                 for (int c = 0; c < CE; ++c) {
                     float err = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                    for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * kst[s][c][j];
                     const float tol = atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c]));
                     const float u = err / tol;
                     if (counted) {
@@ -717,7 +787,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
                         const int c = D + 1 + m;
                         float err = 0.f;
 #pragma unroll
-                        for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * ws.kst[s][c][j];
+                        for (int s = 0; s < 7; ++s) err += (dtf * kCErr[s]) * kst[s][c][j];
                         const float u = err / (atol + rtol * fmaxf(fabsf(y0[c]), fabsf(y1[c])));
                         if (counted) S[3] += (double)u * u;
                     }
@@ -731,12 +801,12 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
                     ++nacc;
                     const int sl[7] = {i_first, 1, 2, 3, 4, 5, i_last};
                     const float wts[7] = {wq[0], wq[1], wq[2], wq[3], wq[4], wq[5], wq[6]};
-                    wide_commit<D>(region, sl, wts, nacc == 1, tid, part);
+                    wide_commit<D, NS, kWideBwdB16>(region, sl, wts, nacc == 1, tid, part, sh.fold_area());
                     if (!(tau_end > tau + dt)) break;
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         y0[c] = y1[c];
-                        ws.kst[0][c][j] = k[c];   // the seventh stage is the next step's first
+                        kst[0][c][j] = k[c];   // the seventh stage is the next step's first
                     }
                     const int t_ = i_first;
                     i_first = i_last;
@@ -783,7 +853,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
         for (int c = 0; c < C; ++c) {
             float s_ = 0.f;
 #pragma unroll
-            for (int s = 0; s < 6; ++s) s_ += (dtf * bc_[s]) * ws.kst[s][c][j];
+            for (int s = 0; s < 6; ++s) s_ += (dtf * bc_[s]) * kst[s][c][j];
             yi[c] = y0[c] + s_;
         }
     }
@@ -797,9 +867,9 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
             const int c = D + 1 + m;
             float mid = 0.f;
 #pragma unroll
-            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * ws.kst[s][c][j];
+            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * kst[s][c][j];
             mid = y0[c] + mid;
-            const float f0 = ws.kst[0][c][j], f1 = ws.kst[6][c][j], u = y0[c], v = y1[c];
+            const float f0 = kst[0][c][j], f1 = kst[6][c][j], u = y0[c], v = y1[c];
             const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
             const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
             const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
@@ -821,19 +891,14 @@ __global__ __launch_bounds__(kThreads) void wide_fixed_bwd_kernel(SolveArgs a, c
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     constexpr int NS = (HUTCH ? 1 : D) + 1;
     constexpr int C = 2 * D + 1;
-    __shared__ WideNetLds<D> net;
-    __shared__ WideWaveLds<C> wl[kNW];
-    __shared__ WideXchg<D, NS> xc;
-    __shared__ float part2[kNW][D][kRows];
+    __shared__ WideBwdShared<D, NS, C, kWideBwdB16> sh;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
-    wide_stage_net(net, a.params, tid);
-    zero_slopes(wl, kNW, tid);
+    sh.stage(a.params, tid);
     __syncthreads();
     const long row = (long)blockIdx.x * kRows + j;
     const bool valid = row < a.rows;
     const bool counted = valid && lane < 16 && w == 0;
     const long rr = valid ? row : a.rows - 1;
-    WideWaveLds<C>& ws = wl[w];
     float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
 
     float y[C], ee[D];
@@ -873,8 +938,8 @@ __global__ __launch_bounds__(kThreads) void wide_fixed_bwd_kernel(SolveArgs a, c
             else wq = (st == 0 || st == 3) ? dt / 8 : 3 * (dt / 8);
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) wts[s_] = st == s_ ? wq : wts[s_];
-            aug_eval_wide<D, HUTCH>(net, ws, xc, part2, a.params, wt, lane, w, sgn * ti, zz, ee, az, al, sgn, wq != 0.f, f, div, vz,
-                                    region + (size_t)st * kWideSlotF<D>, 0);
+            aug_eval_sh<D, HUTCH, kWideBwdB16>(sh, a.params, wt, lane, w, sgn * ti, zz, ee, az, al, sgn, wq != 0.f, f, div, vz,
+                                  region + (size_t)st * kWideSlotF<D>, 0);
 #pragma unroll
             for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
                 f[m] = fmaf(-res, zz[m], f[m]);
@@ -918,7 +983,7 @@ __global__ __launch_bounds__(kThreads) void wide_fixed_bwd_kernel(SolveArgs a, c
             }
         }
         const int sl[7] = {0, 1, 2, 3, 4, 5, 6};
-        wide_commit<D>(region, sl, wts, step == 0, tid, 0);   // slots with weight zero are not read
+        wide_commit<D, NS, kWideBwdB16>(region, sl, wts, step == 0, tid, 0, sh.fold_area());   // slots with weight zero are not read
     }
     if (status == 0 && counted) {
 #pragma unroll
@@ -967,11 +1032,15 @@ size_t wide_bwd_workspace_floats(int D, long rows) {
     long nwg = (rows + kRows - 1) / kRows;
     if (2 * nwg <= kMaxWG) nwg *= 2;   // room for a CNF_FLAG_SPREAD launch
     const size_t sf = D == 1 ? (size_t)kWideSlotF<1> : (size_t)kWideSlotF<2>;
-    return (size_t)2 * kWH * kWH + (size_t)nwg * kWideSlots * sf;
+    return kWideBwdHeadFloats + (size_t)nwg * kWideSlots * sf;
 }
 
 static hipError_t wide_prep(int D, const float* params, float* wt, hipStream_t s) {
-    hipLaunchKernelGGL(wide_transpose_kernel, dim3(kWH / 32, kWH / 32, 2), dim3(32, 8), 0, s, params, D, wt);
+    if (kWideBwdB16)
+        hipLaunchKernelGGL(wide_bwd_pieces_kernel, dim3(2 * 2 * kWT * (kWT / 2) * 64 / 256), dim3(256), 0, s, params, D,
+                           reinterpret_cast<u32x4*>(wt));
+    else
+        hipLaunchKernelGGL(wide_transpose_kernel, dim3(kWH / 32, kWH / 32, 2), dim3(32, 8), 0, s, params, D, wt);
     return hipGetLastError();
 }
 
@@ -979,7 +1048,7 @@ template <int D, bool HUTCH>
 static hipError_t wide_bwd_t(const SolveArgs& a0, float* ws_floats, hipStream_t s) {
     SolveArgs a = a0;
     float* wt = ws_floats;
-    a.slab = ws_floats + (size_t)2 * kWH * kWH;
+    a.slab = ws_floats + kWideBwdHeadFloats;
     hipError_t err = wide_prep(D, a.params, wt, s);
     if (err != hipSuccess) return err;
     const int grid = (int)((a.rows + kRows - 1) / kRows);
@@ -1009,7 +1078,7 @@ template <int D, bool HUTCH>
 static hipError_t wide_fixed_bwd_t(const SolveArgs& a0, float* ws_floats, hipStream_t s) {
     SolveArgs a = a0;
     float* wt = ws_floats;
-    a.slab = ws_floats + (size_t)2 * kWH * kWH;
+    a.slab = ws_floats + kWideBwdHeadFloats;
     hipError_t err = wide_prep(D, a.params, wt, s);
     if (err != hipSuccess) return err;
     const int grid = (int)((a.rows + kRows - 1) / kRows);
@@ -1037,7 +1106,7 @@ static hipError_t wide_aug_t(const SolveArgs& a0, float* ws_floats, float t, con
                              float* f_out, float* nd_out, float* vz_out, hipStream_t s) {
     SolveArgs a = a0;
     float* wt = ws_floats;
-    a.slab = ws_floats + (size_t)2 * kWH * kWH;
+    a.slab = ws_floats + kWideBwdHeadFloats;
     hipError_t err = wide_prep(D, a.params, wt, s);
     if (err != hipSuccess) return err;
     const int grid = (int)((a.rows + kRows - 1) / kRows);

@@ -243,7 +243,26 @@ def test_wide_solve_bwd_matches_oracle_adjoint(dim, hutch, rows):
     assert abs(s_b.n_accepted - bo["n_accepted"]) <= 1 and s_b.n_rejected == bo["n_rejected"]
     assert s_b.evals_run == s_b.nfe == 2 + 6 * (s_b.n_accepted + s_b.n_rejected)
     assert torch.equal(gl0.cpu(), torch.full((rows, 1), 1.0 / rows))
-    assert e_gx < 2e-4 and e_gp < 2e-4
+    if not (e_gx < 2e-4 and e_gp < 2e-4):
+        # The bar is 2e-4 of the oracle's fp32 solve -- unless that solve's own truncation error is larger.  On the
+        # Hutchinson field it is: the oracle's gradient is 4.4e-4 from the float64 adjoint solved at 1e-10, and a kernel
+        # whose last step is 0.2 % shorter (noise-level error ratios steer the step growth here) lands elsewhere inside
+        # that ball (bf16-pipe kernel: 3.3e-4 from the oracle, 1.1e-4 from float64; the fp32-MFMA kernel it replaced:
+        # 0.7e-4 and 4.6e-4; tools/dbg_wide_hutch.py).  Then the kernel must be no further from float64 than the oracle.
+        m64 = _model(dim, hutch, seed=7, scale=2.0).double()
+        f64 = _fn(m64)
+        if hutch:
+            orig64 = f64.before_odeint
+            f64.before_odeint = lambda e_=None: orig64(e=e.double())
+        m64.chain[0].rtol = m64.chain[0].atol = 1e-10
+        x64 = x.double().requires_grad_(True)
+        z64, dl64 = m64(x64, torch.zeros(rows, 1, dtype=torch.float64))
+        (-(oracle.standard_normal_logprob(z64).sum(1, keepdim=True) - dl64).mean()).backward()
+        gp64 = torch.cat([p.grad.reshape(-1) for p in f64.diffeq.parameters()]).float()
+        d_k, d_o = rel_err(gp, gp64), rel_err(gp_ref, gp64)
+        dx_k, dx_o = rel_err(gx, x64.grad.float()), rel_err(xx.grad, x64.grad.float())
+        print("  against the float64 adjoint at 1e-10: grad_theta kernel %.2e oracle %.2e | grad_x kernel %.2e oracle %.2e" % (d_k, d_o, dx_k, dx_o))
+        assert d_o > 2e-4 and d_k <= d_o and dx_k <= dx_o
     off = 0
     for name, p in fn.diffeq.named_parameters():
         k = p.numel()

@@ -20,11 +20,13 @@ with torch.no_grad():
 net, params = fn.net_desc(), fn.diffeq.flat_parameters().detach()
 T = model.chain[0]._end_time()
 opts = nat.make_opts("dopri5", 1e-5, 1e-5)
+SPREAD = (sys.argv[3] if len(sys.argv) > 3 else "spread") == "spread"   # adjoint launched as the training step launches it
+bopts = nat.make_opts("dopri5", 1e-5, 1e-5, flags=nat.FLAG_SPREAD) if SPREAD else opts
 nat.kernel_timing(True)
 for rep in range(3):
     z1, l1, sf = nat.solve_fwd(net, params, x, None, 0.0, T, opts)
     tf = nat.last_kernel_ms()
-    _, _, _, sb = nat.solve_bwd(net, params, z1, l1, z1 / B, torch.full_like(l1, 1.0 / B), 0.0, T, opts)
+    _, _, _, sb = nat.solve_bwd(net, params, z1, l1, z1 / B, torch.full_like(l1, 1.0 / B), 0.0, T, bopts)
     tb = nat.last_kernel_ms()
 sf, sb = nat.Stats(sf), nat.Stats(sb)
 F = 790528
