@@ -45,6 +45,83 @@ struct alignas(16) WideXchgB16 {
     float part[kNW][2 * D][kRows];
 };
 
+typedef uint32_t WideStreamBlk[3][kWT / 2][64][4];   // one stream of a piece buffer
+
+
+// A wave's weight pieces of k-step ks + 1 (4 tiles x 3 pieces, 12 KB per wave from L2) and the buffer's operands of k-step
+// ks + 1 are REQUESTED BEFORE the 72 MFMAs of k-step ks are issued, into the other half of a two-deep register ring, and the
+// order is pinned with sched_group_barrier: left to itself the scheduler, at this kernel's register pressure, sinks the
+// loads to just before their first use and every k-step then waits out an L2 round trip (measured on the first version
+// of this file: 2.9 k clocks per k-step against 1.15 k of matrix work).
+typedef u32x4 WideRing[2][kWTW][3];
+// first k-step (issued before the barrier that releases the buffer they multiply)
+__device__ __forceinline__ void wide_wp_first(const u32x4* __restrict__ wp, WideRing& wb) {
+#pragma unroll
+    for (int T = 0; T < kWTW; ++T)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wb[0][T][p] = wp[((size_t)(T * (kWT / 2) + 0) * 3 + p) * 64];
+}
+
+// acc[T][s] = sum over the 256 inputs of (this wave's 4 output tiles of the matrix whose pieces `wp` streams) x (stream s of
+// the buffer): six piece products per k-step, smallest first, as field_fwd_wide's bf16 path
+template <int NS>
+__device__ __forceinline__ void wide_matmul_b16(const WideStreamBlk* xb, const u32x4* __restrict__ wp, WideRing& wb, int lane,
+                                                f32x4 (&acc)[kWTW][NS]) {
+#pragma unroll
+    for (int T = 0; T < kWTW; ++T)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[T][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef CNF_EXP_WIDE_KSTEPS   // timing experiment: fewer k-steps (wrong results)
+    constexpr int kSteps = CNF_EXP_WIDE_KSTEPS;
+#else
+    constexpr int kSteps = kWT / 2;
+#endif
+    u32x4 bq[2][NS][3];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[0][s][p] = *reinterpret_cast<const u32x4*>(&xb[s][p][0][lane][0]);
+#pragma unroll 2
+    for (int ks = 0; ks < kSteps; ++ks) {
+        const int kn = ks + 1 < kWT / 2 ? ks + 1 : kWT / 2 - 1;   // past the end: a redundant load instead of a branch
+        const int cur = ks & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int T = 0; T < kWTW; ++T)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wb[nxt][T][p] = wp[((size_t)(T * (kWT / 2) + kn) * 3 + p) * 64];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[nxt][s][p] = *reinterpret_cast<const u32x4*>(&xb[s][p][kn][lane][0]);
+#pragma unroll
+        for (int T = 0; T < kWTW; ++T) {
+            bf16x8 aw[3], b[NS][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) aw[p] = __builtin_bit_cast(bf16x8, wb[cur][T][p]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[s][p] = __builtin_bit_cast(bf16x8, bq[cur][s][p]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][2], acc[T][s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[2], b[s][0], acc[T][s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[1], b[s][1], acc[T][s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][1], acc[T][s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[1], b[s][0], acc[T][s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][0], acc[T][s]);
+        }
+        // the k-step as the scheduler must lay it out: the 12 + 3 NS requests first, then the 24 NS MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, kWTW * 3, 0);      // VMEM reads
+        __builtin_amdgcn_sched_group_barrier(0x100, NS * 3, 0);        // LDS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, kWTW * 6 * NS, 0); // MFMA
+    }
+}
+
 template <int D>
 __device__ inline void wide_stage_net(WideNetLds<D>& n, const float* __restrict__ p, int tid) {
     const ParamLayout L = make_layout(D, kWH);

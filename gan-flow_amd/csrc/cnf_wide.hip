@@ -110,51 +110,13 @@ __device__ __forceinline__ void field_fwd_wide(const WideNetLds<D>& n, WS& ws, X
                     }
                 }
             }
-            // weight pieces of this wave's 4 output tiles, k-step ks: [layer][Tout][k-step][piece][lane] x 16 bytes, written
-            // once per launch by wide_split_weights_kernel; ring of two k-steps
+            // weight pieces of this wave's 4 output tiles: [layer][Tout][k-step][piece][lane] x 16 bytes, written once per
+            // launch by wide_split_weights_kernel; requested one k-step ahead (wide_matmul_b16, cnf_wide.h)
             const u32x4* wp = wpieces + ((size_t)(l * kWT + kWTW * wave) * (kWT / 2) * 3) * 64 + lane;
-            u32x4 wb[2][kWTW][3];
-#pragma unroll
-            for (int T = 0; T < kWTW; ++T)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) wb[0][T][p] = wp[((size_t)(T * (kWT / 2) + 0) * 3 + p) * 64];
+            WideRing wb;
+            wide_wp_first(wp, wb);
             __syncthreads();
-#pragma unroll
-            for (int T = 0; T < kWTW; ++T)
-#pragma unroll
-                for (int s = 0; s < NS; ++s) acc[T][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-            for (int ks = 0; ks < kWT / 2; ++ks) {
-                const int kn = ks + 1 < kWT / 2 ? ks + 1 : kWT / 2 - 1;   // past the end: a redundant load instead of a branch
-#pragma unroll
-                for (int T = 0; T < kWTW; ++T)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) wb[(ks + 1) & 1][T][p] = wp[((size_t)(T * (kWT / 2) + kn) * 3 + p) * 64];
-                bf16x8 b[NS][3];
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        b[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xc.xb16[lb][s][p][ks][lane][0]));
-#pragma unroll
-                for (int T = 0; T < kWTW; ++T) {
-                    bf16x8 aw[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) aw[p] = __builtin_bit_cast(bf16x8, wb[ks & 1][T][p]);
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][2], acc[T][s]);
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[2], b[s][0], acc[T][s]);
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[1], b[s][1], acc[T][s]);
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][1], acc[T][s]);
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[1], b[s][0], acc[T][s]);
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][0], acc[T][s]);
-                }
-            }
+            wide_matmul_b16<NS>(xc.xb16[lb], wp, wb, lane, acc);
         } else {
 #pragma unroll
         for (int T = 0; T < kWTW; ++T)

@@ -72,8 +72,6 @@ __global__ __launch_bounds__(256) void wide_bwd_pieces_kernel(const float* __res
     }
 }
 
-typedef uint32_t WideStreamBlk[3][kWT / 2][64][4];   // one stream of a piece buffer
-
 // the wave's 4 values of feature tile tg, one stream, as pieces into the buffer (publish_b16's layout at 8 k-steps)
 __device__ __forceinline__ void wide_publish(WideStreamBlk& blk, int tg, int lane, const f32x4& v) {
     uint32_t pc[4][3];
@@ -85,56 +83,6 @@ __device__ __forceinline__ void wide_publish(WideStreamBlk& blk, int tg, int lan
         o.x = (pc[0][p] >> 16) | pc[1][p];
         o.y = (pc[2][p] >> 16) | pc[3][p];
         *reinterpret_cast<uint2*>(&blk[p][tg >> 1][lane][2 * (tg & 1)]) = o;
-    }
-}
-
-// first k-step of a wave's weight pieces (issued before the barrier that releases the buffer they multiply)
-__device__ __forceinline__ void wide_wp_first(const u32x4* __restrict__ wp, u32x4 (&wb)[2][kWTW][3]) {
-#pragma unroll
-    for (int T = 0; T < kWTW; ++T)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) wb[0][T][p] = wp[((size_t)(T * (kWT / 2) + 0) * 3 + p) * 64];
-}
-
-// acc[T][s] = sum over the 256 inputs of (this wave's 4 output tiles of the matrix whose pieces `wp` streams) x (stream s of
-// the buffer): six piece products per k-step, smallest first, as field_fwd_wide's bf16 path
-template <int NS>
-__device__ __forceinline__ void wide_matmul_b16(const WideStreamBlk* xb, const u32x4* __restrict__ wp, u32x4 (&wb)[2][kWTW][3],
-                                                int lane, f32x4 (&acc)[kWTW][NS]) {
-#pragma unroll
-    for (int T = 0; T < kWTW; ++T)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[T][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int ks = 0; ks < kWT / 2; ++ks) {
-        const int kn = ks + 1 < kWT / 2 ? ks + 1 : kWT / 2 - 1;   // past the end: a redundant load instead of a branch
-#pragma unroll
-        for (int T = 0; T < kWTW; ++T)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wb[(ks + 1) & 1][T][p] = wp[((size_t)(T * (kWT / 2) + kn) * 3 + p) * 64];
-        bf16x8 b[NS][3];
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) b[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xb[s][p][ks][lane][0]));
-#pragma unroll
-        for (int T = 0; T < kWTW; ++T) {
-            bf16x8 aw[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) aw[p] = __builtin_bit_cast(bf16x8, wb[ks & 1][T][p]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][2], acc[T][s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[2], b[s][0], acc[T][s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[1], b[s][1], acc[T][s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][1], acc[T][s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[1], b[s][0], acc[T][s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[T][s] = mfma_b16(aw[0], b[s][0], acc[T][s]);
-        }
     }
 }
 
@@ -409,7 +357,7 @@ __device__ __forceinline__ void aug_eval_wide_b16(WideBwdLds<D, NS>& sh, const f
                 for (int s = 0; s < NS; ++s) wide_store_factor<NS>(slot, l, 1, s, kWTW * wave + T, lane, act[T][s]);
         }
         const u32x4* wp = wpc + ((size_t)(l * kWT + kWTW * wave) * (kWT / 2) * 3) * 64 + lane;
-        u32x4 wb[2][kWTW][3];
+        WideRing wb;
         wide_wp_first(wp, wb);
         f32x4 bias[kWTW];
 #pragma unroll
@@ -617,7 +565,7 @@ __device__ __forceinline__ void aug_eval_wide_b16(WideBwdLds<D, NS>& sh, const f
             }
             // transposed pieces, rows = this wave's INPUT features, streamed like the forward weights
             const u32x4* wp = wpc + kWideSetVecs + ((size_t)(lc * kWT + kWTW * wave) * (kWT / 2) * 3) * 64 + lane;
-            u32x4 wb[2][kWTW][3];
+            WideRing wb;
             wide_wp_first(wp, wb);
             __syncthreads();
 #ifdef CNF_EXP_WIDE_NO_OUTER   // timing experiment: no outer products at all
