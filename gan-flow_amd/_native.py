@@ -52,7 +52,7 @@ STATUS_MESSAGES = {
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
            "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
            "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation", "cnf_debug_eval_field_b16",
-           "cnf_solve_fwd_static", "cnf_static_scratch_bytes", "cnf_gu_sample", "cnf_gu_sample_rows")
+           "cnf_solve_fwd_static", "cnf_static_scratch_bytes", "cnf_gu_sample", "cnf_gu_sample_rows", "cnf_solve_fwd_times")
 
 
 def library_path(act="tanh"):
@@ -87,6 +87,8 @@ def load_library(act="tanh"):
     lib.cnf_debug_eval_field_b16.argtypes = [ND, P, F, P, P, I64, P, P, VP]
     lib.cnf_solve_fwd.restype = ctypes.c_int
     lib.cnf_solve_fwd.argtypes = [ND, P, P, P, P, I64, F, F, SO, P, P, VP, SZ, P, VP]
+    lib.cnf_solve_fwd_times.restype = ctypes.c_int
+    lib.cnf_solve_fwd_times.argtypes = [ND, P, P, P, P, I64, ctypes.POINTER(ctypes.c_float), ctypes.c_int, SO, P, P, P, SZ, P, VP]
     lib.cnf_solve_fwd_static.restype = ctypes.c_int
     lib.cnf_solve_fwd_static.argtypes = [ND, P, P, P, P, I64, F, F, SO, P, P, P, VP]
     lib.cnf_static_scratch_bytes.restype = SZ
@@ -284,6 +286,36 @@ def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None, workspace
         ws = _workspace(lib, net, rows, x.device) if workspace is None else _own_workspace(lib, net, rows, workspace)
         _check(lib.cnf_solve_fwd(ctypes.byref(net), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows, float(t0), float(t1),
                                  ctypes.byref(opts), _ptr(z), _ptr(logp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
+    return z, logp, stats
+
+
+MAX_TIMES = 32   # CNF_MAX_TIMES, include/cnf_hip.h
+
+
+def solve_fwd_times(net, params, x, logp0, times, opts, e=None, stats=None):
+    """cnf_solve_fwd_times: the state at every time of `times` (a sequence of floats, strictly monotonic), one adaptive
+    integration.  Returns (z_t [n, rows, dim], logp_t [n, rows, 1], stats_words); slab 0 is the input."""
+    lib = _lib_for(net)
+    x = _dev(x, "x")
+    rows = x.shape[0]
+    times = [float(t) for t in times]
+    n = len(times)
+    if not 2 <= n <= MAX_TIMES:
+        raise CnfError("between 2 and %d output times (got %d)" % (MAX_TIMES, n))
+    params = _dev(params, "params", (param_count(net),))
+    logp0 = _dev(logp0, "logp0", (rows, 1)) if logp0 is not None else None
+    e = _dev(e, "e", x.shape) if e is not None else None
+    z = torch.empty((n,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+    logp = torch.empty(n, rows, 1, dtype=torch.float32, device=x.device)
+    stats = _stats_block(stats, x.device)
+    host_times = (ctypes.c_float * n)(*times)
+    with torch.cuda.device(x.device):
+        ws = _workspace(lib, net, rows, x.device)
+        _check(lib.cnf_solve_fwd_times(ctypes.byref(net), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows, host_times, n,
+                                       ctypes.byref(opts), _ptr(z), _ptr(logp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
+    if n == 2:   # the library ran the ordinary solve: its one output slab is the state at times[1]
+        z = torch.stack([x, z[0]])
+        logp = torch.stack([logp0 if logp0 is not None else torch.zeros_like(logp[0]), logp[0]])
     return z, logp, stats
 
 

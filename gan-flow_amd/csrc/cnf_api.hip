@@ -330,6 +330,48 @@ int cnf_solve_fwd(const CnfNetDesc* net, const float* params, const float* x, co
                           workspace_bytes, stats, stream);
 }
 
+int cnf_solve_fwd_times(const CnfNetDesc* net, const float* params, const float* x, const float* logp0, const float* e,
+                        int64_t rows, const float* times, int n_times, const CnfSolverOpts* opts, float* z_out, float* logp_out,
+                        void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream) {
+    const char* who = "cnf_solve_fwd_times";
+    if (!times) return fail("%s: NULL pointer", who);
+    if (n_times < 2 || n_times > CNF_MAX_TIMES) return fail("%s: n_times must be in [2, %d] (got %d)", who, CNF_MAX_TIMES, n_times);
+    for (int i = 0; i < n_times; ++i)
+        if (!std::isfinite(times[i])) return fail("%s: times[%d] is not finite", who, i);
+    const bool up = times[1] > times[0];
+    for (int i = 1; i < n_times; ++i)
+        if (!(up ? times[i] > times[i - 1] : times[i] < times[i - 1]))
+            return fail("%s: times must be strictly increasing or strictly decreasing (times[%d] = %g after %g)", who, i,
+                        (double)times[i], (double)times[i - 1]);
+    if (n_times == 2)
+        return solve_fwd_impl(who, false, net, params, x, logp0, e, rows, times[0], times[1], opts, z_out, logp_out, workspace,
+                              workspace_bytes, stats, stream);
+    cnf::SolveArgs a;
+    bool global;
+    if (fill_common(who, net, params, rows, times[0], times[n_times - 1], opts, workspace, workspace_bytes, stats, a, global)) return 1;
+    if (!x || !z_out || !logp_out) return fail("%s: NULL pointer", who);
+    if (opts->solver != CNF_SOLVER_DOPRI5) return fail("%s: several output times are built for dopri5 only", who);
+    if (is_wide(net)) return fail("%s: several output times are built for hidden width 64 only", who);
+    const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
+    if (hutch && !e) return fail("%s: Hutchinson divergence needs the probe e", who);
+    if (global && n_wg(rows) > device_cus())
+        return fail("%s: batch-global step control needs %ld co-resident workgroups but the device has %d compute units; "
+                    "split the batch or use tile_rows=%d", who, (long)n_wg(rows), device_cus(), cnf::kRows);
+    a.x = x;
+    a.logp0 = logp0;
+    a.e = e;
+    a.z_out = z_out;
+    a.logp_out = logp_out;
+    a.n_times = n_times;
+    for (int i = 0; i < n_times; ++i) a.times[i] = times[i];
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = zero_async(workspace, 0, kGranBytes, s);
+    if (err == hipSuccess) err = zero_async(stats, 0, sizeof(CnfStats), s);
+    if (err == hipSuccess) err = cnf::launch_solve_fwd(net->dim, hutch, a, opts->solver, global, s);
+    if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
+    return 0;
+}
+
 // ---- cnf_solve_fwd_static: the forward solve for callers that cannot allocate ------------------------------------------
 // The workspace of the forward solve lives in the library: one file-scope device array per GPU (each device that loads the
 // code object holds its own copy, at its own address, until the process ends).  `scratch` is the HOST-side stand-in of that

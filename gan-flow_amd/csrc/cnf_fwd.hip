@@ -240,6 +240,38 @@ __global__ __launch_bounds__(NW * 64)
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[C];  // initial-step scale, atol + |y0| * rtol
 
+    // Several output times (cnf_solve_fwd_times; torchdiffeq's odeint(func, y0, t) with len(t) > 2): ONE adaptive
+    // integration whose steps ignore the output times; every times[i] is read off the quartic of the accepted step that
+    // first reaches it (advance(next_t): `while next_t > t1: step`, then the interpolant of [t0, t1]).  Slab i of the
+    // outputs holds the state at times[i]; slab 0 is the input, the last slab is written by the ordinary epilogue.
+    const int n_times = a.n_times;
+    const long slab_z = a.rows * D, slab_l = a.rows;
+    int next_i = 1;
+    if (n_times > 2 && counted) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) a.z_out[row * D + m] = y0[m];
+        a.logp_out[row] = y0[D];
+    }
+    // quartic dense output at te inside the accepted step [tau, tau + dt] (B.6): needs y0, y1 and the seven slopes
+    auto dense_output = [&](float te, float (&out)[C]) {
+        const float ta = (float)tau, tb = (float)(tau + dt);
+        const float x = (te - ta) / (tb - ta);
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float mid = 0.f;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * ws.kst[s][c][j];
+            mid = y0[c] + mid;
+            const float f0 = ws.kst[0][c][j], f1 = ws.kst[6][c][j], u = y0[c], v = y1[c];
+            const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
+            const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
+            const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
+            const float cd = dtf * f0;
+            out[c] = ca * x4 + cb * x3 + cc * x2 + cd * x + u;
+        }
+    };
+
     if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
     for (; status == 0;) {
         float zz[D], f[D], div, k[C];
@@ -345,6 +377,17 @@ __global__ __launch_bounds__(NW * 64)
                 const bool accept = (rz <= 1.f) && (rl <= 1.f);
                 if (accept) {
                     ++nacc;
+                    // output times this step reaches, all but the last one (uniform: times and tau are the same everywhere)
+                    while (next_i < n_times - 1 && !((double)(sgn * a.times[next_i]) > tau + dt)) {
+                        float yo[C];
+                        dense_output(sgn * a.times[next_i], yo);
+                        if (counted) {
+#pragma unroll
+                            for (int m = 0; m < D; ++m) a.z_out[next_i * slab_z + row * D + m] = yo[m];
+                            a.logp_out[next_i * slab_l + row] = yo[D];
+                        }
+                        ++next_i;
+                    }
                     if (!(tau_end > tau + dt)) break;  // the step reaches the end time: interpolate below
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
@@ -382,27 +425,14 @@ __global__ __launch_bounds__(NW * 64)
     }
 
     if (status == 0) {
-        // quartic dense output at tau_end inside the accepted step [tau, tau+dt] (B.6)
-        const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
-        const float x = (te - ta) / (tb - ta);
-        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            float mid = 0.f;
-#pragma unroll
-            for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * ws.kst[s][c][j];
-            mid = y0[c] + mid;
-            const float f0 = ws.kst[0][c][j], f1 = ws.kst[6][c][j], u = y0[c], v = y1[c];
-            const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
-            const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
-            const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
-            const float cd = dtf * f0;
-            y1[c] = ca * x4 + cb * x3 + cc * x2 + cd * x + u;
-        }
+        // the state at the end time, off the last accepted step's quartic
+        float yo[C];
+        dense_output((float)tau_end, yo);
+        const long last = n_times > 2 ? n_times - 1 : 0;
         if (counted) {
 #pragma unroll
-            for (int m = 0; m < D; ++m) a.z_out[row * D + m] = y1[m];
-            a.logp_out[row] = y1[D];
+            for (int m = 0; m < D; ++m) a.z_out[last * slab_z + row * D + m] = yo[m];
+            a.logp_out[last * slab_l + row] = yo[D];
         }
     }
     if (lane == 0 && (!GLOBAL || (blockIdx.x == 0 && w == 0) || status != 0)) {

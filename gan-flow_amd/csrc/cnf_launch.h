@@ -7,6 +7,8 @@
 
 namespace cnf {
 
+constexpr int kMaxTimes = CNF_MAX_TIMES;   // include/cnf_hip.h
+
 struct SolveArgs {
     const float* params;
     const float* x;       // state at t0 (rows x D)
@@ -39,6 +41,10 @@ struct SolveArgs {
     int adj_all;          // adjoint, CNF_FLAG_ADJ_CONTROL_ALL: a_z and a_logp under step control as well (cnf_device.h)
     int fwd4;             // CNF_FLAG_FWD_FOUR_WAVES: the four-wave forward kernel where the eight-wave one would run
     const CnfStats* after;  // CnfSolverOpts.after (nullable): exit at once with that block's status when it is non-zero
+    // cnf_solve_fwd_times (dopri5_kernel, cnf_fwd.hip): n_times > 2 = the state at every times[i] goes to slab i of z_out /
+    // logp_out (slab 0 = the input; t0 = times[0], t1 = times[n_times - 1]); 0 = the ordinary solve
+    int n_times;
+    float times[kMaxTimes];
 };
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,

@@ -38,6 +38,41 @@ class _Solve(torch.autograd.Function):
         return gx, gl, gp, None, None, None, None, None, None
 
 
+class _SolveTimes(torch.autograd.Function):
+    """(z0, logp0, theta) -> the state at every time of `times`, stacked (odeint with len(t) > 2): one adaptive forward
+    integration (cnf_solve_fwd_times); backward = OdeintAdjointMethod.backward's loop over the intervals, last first,
+    each an adjoint solve started from the stored state at its upper time, the output cotangent of that time added to
+    the one carried back (oracle/odeint.py::_Adjoint.backward restates it)."""
+
+    @staticmethod
+    def forward(ctx, z, logp, flat_params, block, times, opts, net, e):
+        z_t, logp_t, stats = _native.solve_fwd_times(net, flat_params.detach(), z.detach(), logp.detach(), times, opts, e)
+        block._after_solve(stats, backward=False)
+        ctx.block, ctx.times, ctx.opts, ctx.net = block, tuple(times), opts, net
+        ctx.fwd_stats = stats
+        ctx.save_for_backward(z_t, logp_t, flat_params.detach(), e if e is not None else z.new_zeros(0))
+        return z_t, logp_t
+
+    @staticmethod
+    def backward(ctx, grad_z, grad_logp):
+        z_t, logp_t, flat_params, e = ctx.saved_tensors
+        e = e if e.numel() else None
+        grad_z = torch.zeros_like(z_t) if grad_z is None else grad_z
+        grad_logp = torch.zeros_like(logp_t) if grad_logp is None else grad_logp
+        n = len(ctx.times)
+        a_z, a_l = grad_z[n - 1].contiguous(), grad_logp[n - 1].contiguous()
+        g_theta = torch.zeros_like(flat_params)
+        after = ctx.fwd_stats
+        for i in range(n - 1, 0, -1):
+            gx, gl, gp, stats = _native.solve_bwd(ctx.net, flat_params, z_t[i].contiguous(), logp_t[i].contiguous(), a_z, a_l,
+                                                  ctx.times[i - 1], ctx.times[i], _native.with_after(ctx.opts, after), e)
+            ctx.block._after_solve(stats, backward=True)
+            after = stats
+            a_z, a_l = gx + grad_z[i - 1], gl + grad_logp[i - 1]
+            g_theta = g_theta + gp
+        return a_z, a_l, g_theta, None, None, None, None, None
+
+
 class CNF(nn.Module):
     def __init__(self, odefunc, T=1.0, train_T=False, regularization_fns=None, solver="dopri5", atol=1e-5, rtol=1e-5):
         super().__init__()
@@ -97,9 +132,10 @@ class CNF(nn.Module):
         if integration_times is None:
             t0, t1 = 0.0, self._end_time()
         else:
-            if len(integration_times) != 2:
-                raise NotImplementedError("the fused integrator returns the state at the end time only")
-            t0, t1 = float(integration_times[0]), float(integration_times[1])
+            if len(integration_times) < 2:
+                raise ValueError("integration_times needs at least two times")
+            # more than two times: forward() passes the whole list to cnf_solve_fwd_times; (t0, t1) are its ends
+            t0, t1 = float(integration_times[0]), float(integration_times[-1])
         if reverse:
             t0, t1 = t1, t0
         inner = _inner(self.odefunc)
@@ -123,7 +159,14 @@ class CNF(nn.Module):
         net, t0, t1, opts, e = self.solve_plan(z, integration_times, reverse)
         _logpz = torch.zeros(z.shape[0], 1, device=z.device, dtype=z.dtype) if logpz is None else logpz
         flat = _inner(self.odefunc).diffeq.flat_parameters()
-        z_t, logpz_t = _Solve.apply(z, _logpz, flat, self, t0, t1, opts, net, e)
+        if integration_times is not None and len(integration_times) > 2:
+            # the reference returns the states stacked over t then (`state_t = odeint(...)`, no `[1]`)
+            times = [float(t) for t in integration_times]
+            if reverse:
+                times = times[::-1]   # _flip(integration_times, 0)
+            z_t, logpz_t = _SolveTimes.apply(z, _logpz, flat, self, times, opts, net, e)
+        else:
+            z_t, logpz_t = _Solve.apply(z, _logpz, flat, self, t0, t1, opts, net, e)
         self.regularization_states = ()
         return (z_t, logpz_t) if logpz is not None else z_t
 

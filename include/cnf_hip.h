@@ -173,6 +173,24 @@ int cnf_solve_fwd_static(const CnfNetDesc *net, const float *params, const float
                          const float *e, int64_t rows, float t0, float t1, const CnfSolverOpts *opts,
                          float *z_out, float *logp_out, CnfStats *stats, void *stream);
 
+/* Forward solve with SEVERAL output times: odeint(odefunc, (x, logp0), times) with len(times) > 2 -- what CNF.forward
+ * passes on when the caller gives it `integration_times` (ffjord/lib/layers/cnf.py: `state_t = odeint(...)`, returned
+ * stacked over t; the call /root/reference/requirements.txt:17 provides).  ONE adaptive integration from times[0] to
+ * times[n_times - 1] whose steps ignore the output times; the state at every times[i] is read off the quartic interpolant
+ * of the accepted step that first reaches it (torchdiffeq 0.0.1: `while next_t > rk_state.t1: step`, then
+ * `_interp_evaluate`).  times: HOST array of n_times floats, strictly increasing or strictly decreasing,
+ * 2 <= n_times <= CNF_MAX_TIMES (copied into the kernel's arguments: no device copy, capturable).
+ * z_out: n_times x rows x dim, logp_out: n_times x rows; slab 0 is the input state.
+ * dopri5 only; hidden width 64 (the one-tile-per-wave kernels of csrc/cnf_fwd.hip: batch-global control up to 16 384 rows,
+ * tile-local any number).  The adjoint of such a solve is a chain of cnf_solve_bwd calls over the intervals
+ * [times[i-1], times[i]], i = n_times - 1 .. 1, each started from slab i with the output cotangent of slab i added to the
+ * carried one -- exactly OdeintAdjointMethod.backward's loop (gan_flow_amd/lib/layers/cnf.py::_SolveTimes).            */
+#define CNF_MAX_TIMES 32
+int cnf_solve_fwd_times(const CnfNetDesc *net, const float *params, const float *x, const float *logp0,
+                        const float *e, int64_t rows, const float *times, int n_times, const CnfSolverOpts *opts,
+                        float *z_out, float *logp_out, void *workspace, size_t workspace_bytes,
+                        CnfStats *stats, void *stream);
+
 /* One evaluation of the adjoint's augmented dynamics (the closure `augmented_dynamics` inside
  * OdeintAdjointMethod.backward, a10): given z, a_z, a_logp returns
  *   f, -div, vjp_z = -(a_z . df/dz) + a_logp * d(div)/dz   (rows x dim)
