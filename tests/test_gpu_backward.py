@@ -91,7 +91,7 @@ def _oracle_train_grads(m, x):
     m.train()
     m.zero_grad()
     xx = x.clone().requires_grad_(True)
-    z, dl = m(xx, torch.zeros(x.shape[0], 1))
+    z, dl = m(xx, torch.zeros(x.shape[0], 1, dtype=x.dtype))
     loss = _loss(z, dl)
     loss.backward()
     blk = m.chain[0]
@@ -735,12 +735,26 @@ def test_other_nonlinearities(act, dim, hidden, hutch, rows):
     nb, nb_ref = st["backward"].n_accepted + st["backward"].n_rejected, st_ref["backward"]["n_accepted"] + st_ref["backward"]["n_rejected"]
     assert abs(nb - nb_ref) <= 1
     assert abs(loss.item() - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
-    # same step sequence: rounding-level agreement; one step more or fewer, or elu's kink in act'' met at different
-    # points of the two step sequences: agreement at the level the 1e-5 tolerances leave
+    # same step sequence: rounding-level agreement (2e-4); one step more or fewer: agreement at the level the 1e-5
+    # tolerances leave (2e-3).  A case outside its bar passes only if the float64 adjoint (same weights, tolerances
+    # 1e-10) shows that the fp32 ORACLE is that far from the truth itself and the kernel no further than twice that:
+    # elu at d = 16 (Hutchinson), whose act'' jumps at 0 -- rows that cross the kink inside a step pick up O(dt) differences
+    # from where fp32 rounding puts the crossing (measured: kernel 3.2e-4 from the oracle; every other case < 1.1e-4).
     e_gp, e_gx = rel_err(gp, gp_ref), rel_err(xp.grad, gx_ref)
     print("%s d=%d: adjoint attempts hip %d oracle %d, grad_theta %.2e grad_x %.2e" % (act, dim, nb, nb_ref, e_gp, e_gx))
-    bar = 2e-4 if (nb == nb_ref and act != "elu") else 2e-3
-    assert e_gp < bar and e_gx < bar
+    bar = 2e-4 if nb == nb_ref else 2e-3
+    if not (e_gp < bar and e_gx < bar):
+        m64 = oracle_random_model(dim, seed=23, scale=1.5, divergence_fn=div, hidden_dims=dims, nonlinearity=act).double()
+        if hutch:
+            f64 = _odefunc(m64)
+            orig64 = f64.before_odeint
+            f64.before_odeint = lambda e_=None: orig64(e=e.double())
+        m64.chain[0].rtol = m64.chain[0].atol = 1e-10
+        _, _, _, gx64, gp64, _ = _oracle_train_grads(m64, x.double())
+        d_k, d_o = rel_err(gp, gp64.float()), rel_err(gp_ref, gp64.float())
+        dx_k, dx_o = rel_err(xp.grad, gx64.float()), rel_err(gx_ref, gx64.float())
+        print("   against the float64 adjoint at 1e-10: grad_theta kernel %.2e oracle %.2e | grad_x kernel %.2e oracle %.2e" % (d_k, d_o, dx_k, dx_o))
+        assert max(d_o, dx_o) > 0.5 * bar and d_k <= 2 * d_o and dx_k <= 2 * dx_o
 
 
 @pytest.mark.parametrize("solver", ["rk4", "euler", "midpoint"])
