@@ -26,6 +26,26 @@ class CnfSolverOpts(ctypes.Structure):
                 ("flags", ctypes.c_int32), ("after", ctypes.c_void_p)]
 
 
+MAX_REG = 2                      # CNF_MAX_REG
+REG_KINDS = {"l1": 1, "l2": 2}   # CNF_REG_L1, CNF_REG_L2
+
+
+class CnfRegDesc(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("kind", ctypes.c_int32 * MAX_REG)]
+
+
+def reg_desc(kinds):
+    """kinds: a sequence of 'l1' / 'l2' in the order of the reference's regularization_fns."""
+    kinds = list(kinds)
+    if not 1 <= len(kinds) <= MAX_REG or any(k not in REG_KINDS for k in kinds):
+        raise CnfError("regularisers built into the HIP path: up to %d of %s (got %r)" % (MAX_REG, sorted(REG_KINDS), kinds))
+    d = CnfRegDesc()
+    d.n = len(kinds)
+    for i, k in enumerate(kinds):
+        d.kind[i] = REG_KINDS[k]
+    return d
+
+
 GU_MAX_MIXTURE = 16
 
 
@@ -52,7 +72,8 @@ STATUS_MESSAGES = {
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
            "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",
            "cnf_debug_kernel_timing", "cnf_debug_last_kernel_ms", "cnf_activation", "cnf_debug_eval_field_b16",
-           "cnf_solve_fwd_static", "cnf_static_scratch_bytes", "cnf_gu_sample", "cnf_gu_sample_rows", "cnf_solve_fwd_times")
+           "cnf_solve_fwd_static", "cnf_static_scratch_bytes", "cnf_gu_sample", "cnf_gu_sample_rows", "cnf_solve_fwd_times",
+           "cnf_solve_fwd_reg", "cnf_solve_bwd_reg")
 
 
 def library_path(act="tanh"):
@@ -87,6 +108,11 @@ def load_library(act="tanh"):
     lib.cnf_debug_eval_field_b16.argtypes = [ND, P, F, P, P, I64, P, P, VP]
     lib.cnf_solve_fwd.restype = ctypes.c_int
     lib.cnf_solve_fwd.argtypes = [ND, P, P, P, P, I64, F, F, SO, P, P, VP, SZ, P, VP]
+    RD = ctypes.POINTER(CnfRegDesc)
+    lib.cnf_solve_fwd_reg.restype = ctypes.c_int
+    lib.cnf_solve_fwd_reg.argtypes = [ND, RD, P, P, P, P, I64, F, F, SO, P, P, P, P, SZ, P, VP]
+    lib.cnf_solve_bwd_reg.restype = ctypes.c_int
+    lib.cnf_solve_bwd_reg.argtypes = [ND, RD, P, P, P, P, P, P, P, P, I64, F, F, SO, P, P, P, P, SZ, P, VP]
     lib.cnf_solve_fwd_times.restype = ctypes.c_int
     lib.cnf_solve_fwd_times.argtypes = [ND, P, P, P, P, I64, ctypes.POINTER(ctypes.c_float), ctypes.c_int, SO, P, P, P, SZ, P, VP]
     lib.cnf_solve_fwd_static.restype = ctypes.c_int
@@ -287,6 +313,52 @@ def solve_fwd(net, params, x, logp0, t0, t1, opts, e=None, stats=None, workspace
         _check(lib.cnf_solve_fwd(ctypes.byref(net), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows, float(t0), float(t1),
                                  ctypes.byref(opts), _ptr(z), _ptr(logp), _ptr(ws), ws.numel(), _ptr(stats), _stream()), lib)
     return z, logp, stats
+
+
+def solve_fwd_reg(net, reg, params, x, logp0, t0, t1, opts, e=None, stats=None):
+    """cnf_solve_fwd_reg: solve_fwd of the regularised dynamics.  Returns (z, logp, reg_states[reg.n], stats_words)."""
+    lib = _lib_for(net)
+    x = _dev(x, "x")
+    rows = x.shape[0]
+    params = _dev(params, "params", (param_count(net),))
+    logp0 = _dev(logp0, "logp0", (rows, 1)) if logp0 is not None else None
+    e = _dev(e, "e", x.shape) if e is not None else None
+    z = torch.empty_like(x)
+    logp = torch.empty(rows, 1, dtype=torch.float32, device=x.device)
+    regs = torch.empty(reg.n, dtype=torch.float32, device=x.device)
+    stats = _stats_block(stats, x.device)
+    with torch.cuda.device(x.device):
+        ws = _workspace(lib, net, rows, x.device)
+        _check(lib.cnf_solve_fwd_reg(ctypes.byref(net), ctypes.byref(reg), _ptr(params), _ptr(x), _ptr(logp0), _ptr(e), rows,
+                                     float(t0), float(t1), ctypes.byref(opts), _ptr(z), _ptr(logp), _ptr(regs), _ptr(ws),
+                                     ws.numel(), _ptr(stats), _stream()), lib)
+    return z, logp, regs, stats
+
+
+def solve_bwd_reg(net, reg, params, z1, logp1, reg_t1, grad_z1, grad_logp1, grad_reg, t0, t1, opts, e=None, stats=None):
+    """cnf_solve_bwd_reg: the adjoint pass of the regularised dynamics.  reg_t1: the regularisation states at t1 (reg.n
+    floats on the device), grad_reg: dL/d(those states).  Returns (grad_x, grad_logp0, grad_params, stats_words)."""
+    lib = _lib_for(net)
+    z1 = _dev(z1, "z1")
+    rows = z1.shape[0]
+    params = _dev(params, "params", (param_count(net),))
+    logp1 = _dev(logp1, "logp1", (rows, 1))
+    grad_z1 = _dev(grad_z1, "grad_z1", z1.shape)
+    grad_logp1 = _dev(grad_logp1, "grad_logp1", (rows, 1))
+    reg_t1 = _dev(reg_t1, "reg_t1", (reg.n,))
+    grad_reg = _dev(grad_reg, "grad_reg", (reg.n,))
+    e = _dev(e, "e", z1.shape) if e is not None else None
+    gx = torch.empty_like(z1)
+    gl = torch.empty_like(logp1)
+    gp = torch.empty_like(params)
+    stats = _stats_block(stats, z1.device)
+    with torch.cuda.device(z1.device):
+        ws = _workspace(lib, net, rows, z1.device)
+        _check(lib.cnf_solve_bwd_reg(ctypes.byref(net), ctypes.byref(reg), _ptr(params), _ptr(z1), _ptr(logp1), _ptr(e),
+                                     _ptr(reg_t1), _ptr(grad_z1), _ptr(grad_logp1), _ptr(grad_reg), rows, float(t0), float(t1),
+                                     ctypes.byref(opts), _ptr(gx), _ptr(gl), _ptr(gp), _ptr(ws), ws.numel(), _ptr(stats),
+                                     _stream()), lib)
+    return gx, gl, gp, stats
 
 
 MAX_TIMES = 32   # CNF_MAX_TIMES, include/cnf_hip.h

@@ -15,6 +15,7 @@ hipError_t launch_eval_aug(int D, bool hutch, const SolveArgs& a, float t, const
 hipError_t launch_solve_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 hipError_t launch_fixed_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 hipError_t launch_split16_fixed_bwd(const SolveArgs& a, hipStream_t s);
+hipError_t launch_reg_mean(const float* reg_rows, long rows, int nreg, float* out, hipStream_t s);
 hipError_t launch_wide_fixed_bwd(int D, bool hutch, const SolveArgs& a, float* ws_floats, hipStream_t s);
 // feature-split (one tile per workgroup) variants, cnf_split.hip
 hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
@@ -569,6 +570,87 @@ int cnf_solve_bwd(const CnfNetDesc* net, const float* params, const float* z1, c
     cnf::SolveArgs a;
     return solve_bwd_impl("cnf_solve_bwd", false, net, params, z1, logp1, e, grad_z1, grad_logp1, rows, t0, t1, opts, grad_x,
                           grad_logp0, grad_params, nullptr, workspace, workspace_bytes, stats, stream, a);
+}
+
+// ---- regularised dynamics (CnfRegDesc, include/cnf_hip.h) ---------------------------------------------------------------
+static int check_reg(const char* who, const CnfNetDesc* net, const CnfRegDesc* reg, int64_t rows, const CnfSolverOpts* opts) {
+    if (check_net(net)) return 1;
+    if (!reg || !opts) return fail("%s: NULL pointer", who);
+    if (reg->n < 1 || reg->n > CNF_MAX_REG) return fail("%s: reg->n must be 1..%d (got %d)", who, CNF_MAX_REG, reg->n);
+    for (int k = 0; k < reg->n; ++k)
+        if (reg->kind[k] != CNF_REG_L1 && reg->kind[k] != CNF_REG_L2)
+            return fail("%s: reg->kind[%d] = %d: built are CNF_REG_L1 and CNF_REG_L2", who, k, reg->kind[k]);
+    if (is_wide(net) || net->dim > 2) return fail("%s: regularised dynamics are built for hidden width 64 and dim 1 | 2", who);
+    if (opts->solver != CNF_SOLVER_DOPRI5 || opts->tile_rows != 0)
+        return fail("%s: regularised dynamics are built for dopri5 with batch-global step control", who);
+    if (opts->flags & CNF_FLAG_ADJ_CONTROL_ALL) return fail("%s: CNF_FLAG_ADJ_CONTROL_ALL is not built for regularised dynamics", who);
+    if (rows > 0 && (n_wg(rows) > cnf::kMaxWG || n_wg(rows) > device_cus()))
+        return fail("%s: at most %ld rows per solve on this device (got %ld)", who,
+                    (long)cnf::kRowsPerWG * (cnf::kMaxWG < device_cus() ? cnf::kMaxWG : device_cus()), (long)rows);
+    return 0;
+}
+
+int cnf_solve_fwd_reg(const CnfNetDesc* net, const CnfRegDesc* reg, const float* params, const float* x, const float* logp0,
+                      const float* e, int64_t rows, float t0, float t1, const CnfSolverOpts* opts, float* z_out, float* logp_out,
+                      float* reg_out, void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream) {
+    const char* who = "cnf_solve_fwd_reg";
+    if (check_reg(who, net, reg, rows, opts)) return 1;
+    cnf::SolveArgs a;
+    bool global;
+    if (fill_common(who, net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
+    if (!x || !z_out || !logp_out || !reg_out) return fail("%s: NULL pointer", who);
+    const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
+    if (hutch && !e) return fail("%s: Hutchinson divergence needs the probe e", who);
+    a.x = x;
+    a.logp0 = logp0;
+    a.e = e;
+    a.z_out = z_out;
+    a.logp_out = logp_out;
+    a.nreg = reg->n;
+    for (int k = 0; k < reg->n; ++k) a.reg_kind[k] = reg->kind[k];
+    a.reg_rows = a.slab;   // reg->n x rows floats: the head of the gradient region, which a forward solve does not use
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = zero_async(workspace, 0, kGranBytes, s);
+    if (err == hipSuccess) err = zero_async(stats, 0, sizeof(CnfStats), s);
+    if (err == hipSuccess) err = cnf::launch_solve_fwd(net->dim, hutch, a, CNF_SOLVER_DOPRI5, true, s);
+    if (err == hipSuccess) err = cnf::launch_reg_mean(a.reg_rows, rows, reg->n, reg_out, s);
+    if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
+    return 0;
+}
+
+int cnf_solve_bwd_reg(const CnfNetDesc* net, const CnfRegDesc* reg, const float* params, const float* z1, const float* logp1,
+                      const float* e, const float* reg_t1, const float* grad_z1, const float* grad_logp1, const float* grad_reg,
+                      int64_t rows, float t0, float t1, const CnfSolverOpts* opts, float* grad_x, float* grad_logp0,
+                      float* grad_params, void* workspace, size_t workspace_bytes, CnfStats* stats, void* stream) {
+    const char* who = "cnf_solve_bwd_reg";
+    if (check_reg(who, net, reg, rows, opts)) return 1;
+    cnf::SolveArgs a;
+    bool global;
+    if (fill_common(who, net, params, rows, t0, t1, opts, workspace, workspace_bytes, stats, a, global)) return 1;
+    if (!z1 || !logp1 || !reg_t1 || !grad_z1 || !grad_logp1 || !grad_reg || !grad_x || !grad_logp0 || !grad_params)
+        return fail("%s: NULL pointer", who);
+    const bool hutch = (net->divergence & ~CNF_DIV_RESIDUAL) == CNF_DIV_HUTCHINSON;
+    if (hutch && !e) return fail("%s: Hutchinson divergence needs the probe e", who);
+    a.x = z1;
+    a.logp0 = logp1;
+    a.e = e;
+    a.grad_z1 = grad_z1;
+    a.grad_logp1 = grad_logp1;
+    a.grad_x = grad_x;
+    a.grad_logp0 = grad_logp0;
+    a.grad_params = grad_params;
+    a.nreg = reg->n;
+    for (int k = 0; k < reg->n; ++k) a.reg_kind[k] = reg->kind[k];
+    a.reg_val = reg_t1;
+    a.reg_cot = grad_reg;
+    hipStream_t s = (hipStream_t)stream;
+    // the one-tile-per-wave adjoint: n_wg gradient slabs, accumulated into (cnf_workspace_bytes covers them for any row count)
+    const size_t P = (size_t)cnf::make_layout(net->dim, net->hidden).total;
+    hipError_t err = zero_async(workspace, 0, kGranBytes + align16((size_t)n_wg(rows) * P * sizeof(float)), s);
+    if (err == hipSuccess) err = zero_async(stats, 0, sizeof(CnfStats), s);
+    if (err == hipSuccess) err = cnf::launch_solve_bwd(net->dim, hutch, a, s);
+    if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
+    return 0;
 }
 
 int cnf_solve_bwd_train(const CnfNetDesc* net, float* params, const float* z1, const float* logp1, const float* e,

@@ -113,11 +113,22 @@ __device__ inline void commit_step(BwdWaveLds<D>* wl, const BigAcc& acc, float* 
 // in : t, z, e (Hutchinson probe), a_z, a_l (adjoints of z and logp for this lane's row), w (weight of this
 //      evaluation in the parameter-gradient quadrature; with_theta=false skips that work)
 // out: f, div (as field_fwd), vz = -(a_z . df/dz) + a_l * d(div)/dz; acc += w * d/dtheta summed over rows
+// regularised dynamics (cnf_solve_bwd_reg): the constant adjoints of the regulariser states enter the sweep as one more
+// cotangent on dz/dt, c_k * d integrand_k / d(dz/dt) with c_k = dL/dr_k / rows (the states are batch means)
+struct RegCot {
+    int nreg;
+    int kind[CNF_MAX_REG];
+    float c[CNF_MAX_REG];
+    float res;   // 1: the dynamics are f(z) - z (CNF_DIV_RESIDUAL), the regularisers see that difference
+};
+
+// rc / reg_extra (nullable): RegCot above; reg_extra[D] receives the extra cotangent (the caller's residual term needs it)
 template <int D, bool HUTCH>
 __device__ __forceinline__ void aug_eval(const NetLds<D>& n, const BwdNetLds& nt, BwdWaveLds<D>& ws, int lane, float t,
                                          const float (&z)[D], const float (&e)[D], const float (&az)[D], float al,
                                          float w, bool with_theta, float (&f)[D], float& div, float (&vz)[D],
-                                         BigAcc& acc, BwdNetLds& sh, int wave) {
+                                         BigAcc& acc, BwdNetLds& sh, int wave, const RegCot* rc = nullptr,
+                                         float* reg_extra = nullptr) {
     constexpr int NT = HUTCH ? 1 : D;
     constexpr int NS = NT + 1;
     using SI = SmallIdx<D>;
@@ -246,6 +257,17 @@ __device__ __forceinline__ void aug_eval(const NetLds<D>& n, const BwdNetLds& nt
     float lf[D];
 #pragma unroll
     for (int m = 0; m < D; ++m) lf[m] = -az[m];
+    if (rc) {
+        float dx[D], extra[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) dx[m] = fmaf(-rc->res, z[m], f[m]);
+        reg_cotangent<D>(rc->nreg, rc->kind, rc->c, dx, extra);
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            lf[m] = -(az[m] + extra[m]);
+            if (reg_extra) reg_extra[m] = extra[m];
+        }
+    }
     const float ld = al;
     float cot[NS][16];
 
@@ -534,7 +556,8 @@ __global__ __launch_bounds__(kThreads) void aug_kernel(SolveArgs a, float t, con
 }
 
 // ---- the adjoint solve -------------------------------------------------------------------------------------
-template <int D, bool HUTCH>
+// REG: regularised dynamics (cnf_solve_bwd_reg) -- an instance of its own, so that the ordinary adjoint's registers are its own
+template <int D, bool HUTCH, bool REG = false>
 __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLds<D> net;
@@ -588,6 +611,24 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
     BigAcc acc;
     acc.zero();
 
+    // regularised dynamics (cnf_solve_bwd_reg).  The regulariser states ride along in the reference's augmented state with
+    // tolerances of 1e20: they never fail an attempt and nothing reads them at t0, so they are not integrated here.  What
+    // remains of them: (i) their constant adjoints, one more cotangent on dz/dt in every evaluation (RegCot); (ii) the first
+    // step, whose heuristic weighs their values at t1 and their slopes like any other controlled tensor.
+    const int nreg = REG ? a.nreg : 0;
+    RegCot rcot{nreg, {a.reg_kind[0], a.reg_kind[1]}, {0.f, 0.f}, res};
+    float reg_scale[CNF_MAX_REG] = {atol, atol}, d0r[CNF_MAX_REG] = {0.f, 0.f}, d1r[CNF_MAX_REG] = {0.f, 0.f}, kr_f0[CNF_MAX_REG] = {0.f, 0.f};
+    if (nreg) {
+#pragma unroll
+        for (int q_ = 0; q_ < CNF_MAX_REG; ++q_)
+            if (q_ < nreg) {
+                rcot.c[q_] = valid ? a.reg_cot[q_] / (float)a.rows : 0.f;   // rows past the batch are clamped copies: no cotangent
+                const float r = a.reg_val[q_];
+                reg_scale[q_] = atol + fabsf(r) * rtol;
+                d0r[q_] = fabsf(r / reg_scale[q_]);
+            }
+    }
+
     if (a.after) status = a.after->status;   // CnfSolverOpts.after: the solve whose output this one consumes failed
     for (; status == 0;) {
         float zz[D], az[D], f[D], vz[D], div, k[C];
@@ -599,15 +640,24 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
         }
         const bool with_theta = phase == PH_STAGE && ws.wq[stage] != 0.f;
         // initial-step evaluations only need (f, div); the sweep still runs (one code path), its outputs are unused
+        float rextra[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) rextra[m] = 0.f;
         aug_eval<D, HUTCH>(net, netT, ws, lane, sgn * ti, zz, ee, az, al, phase == PH_STAGE ? sgn * ws.wq[stage] : 0.f,
-                           with_theta, f, div, vz, acc, netT, w);
+                           with_theta, f, div, vz, acc, netT, w, (REG && nreg) ? &rcot : nullptr, REG ? rextra : nullptr);
         #pragma unroll
         for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
             f[m] = fmaf(-res, zz[m], f[m]);
-            vz[m] = fmaf(res, az[m], vz[m]);
+            vz[m] = fmaf(res, az[m] + rextra[m], vz[m]);
         }
         div -= res * (float)D;
         ++nrun;
+        float kr[CNF_MAX_REG] = {0.f, 0.f};   // slopes of the regulariser states, for the first step only
+        if (nreg && phase != PH_STAGE) {
+#pragma unroll
+            for (int q_ = 0; q_ < CNF_MAX_REG; ++q_)
+                if (q_ < nreg) kr[q_] = sgn * reg_integrand<D>(a.reg_kind[q_], f);
+        }
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             k[m] = sgn * f[m];
@@ -643,7 +693,20 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
                 d0al = (float)sqrt(S2[2] / nl);
                 if (tid == 0) red.keep[0] = d1a;   // read after the next reduction's barriers
             }
-            h0 = initial_h0(d0z, d0l, d1z, d1l, a.adj_all != 0, d0a, d1a, d0al);
+            if (nreg) {   // (not combined with CNF_FLAG_ADJ_CONTROL_ALL: the API refuses that)
+                double S2[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) {
+                    kr_f0[q_] = kr[q_];
+                    if (counted) S2[q_] = (double)kr[q_];
+                }
+                if (!wg_allreduce4(gs, red, S2, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) d1r[q_] = fabsf((float)(S2[q_] / nl) / reg_scale[q_]);
+                h0 = initial_h0_reg(d0z, d0l, d1z, d1l, nreg, d0r, d1r);
+            } else {
+                h0 = initial_h0(d0z, d0l, d1z, d1l, a.adj_all != 0, d0a, d1a, d0al);
+            }
             if (h0 < INFINITY) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) yi[c] = y0[c] + h0 * k[c];
@@ -667,10 +730,21 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
                     S[3] += (double)u * u;
                 }
             }
+            if (nreg && counted) {   // the change of the regularisers' batch means, in the two slots this sum leaves free
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) S[2 + q_] = (double)(kr[q_] - kr_f0[q_]);
+            }
             if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
-            const float d2a = (float)sqrt(S[3] / nz) / h0;
-            dt = (double)initial_dt(h0, d1z, d1l, d2z, d2l, a.adj_all != 0, a.adj_all ? red.keep[0] : 0.f, d2a);
+            if (nreg) {
+                float d2r[CNF_MAX_REG];
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) d2r[q_] = fabsf((float)(S[2 + q_] / nl) / reg_scale[q_]) / h0;
+                dt = (double)initial_dt_reg(h0, d1z, d1l, d2z, d2l, nreg, d1r, d2r);
+            } else {
+                const float d2a = (float)sqrt(S[3] / nz) / h0;
+                dt = (double)initial_dt(h0, d1z, d1l, d2z, d2l, a.adj_all != 0, a.adj_all ? red.keep[0] : 0.f, d2a);
+            }
             restart = true;
         } else {
             // slope number stage+1 (stage 0 = the re-evaluated first slope)
@@ -961,12 +1035,14 @@ hipError_t launch_eval_aug(int D, bool hutch, const SolveArgs& a, float t, const
 template <int D, bool HUTCH>
 static hipError_t launch_solve_bwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRowsPerWG - 1) / kRowsPerWG);
-    dbg_timing_begin(s);
     {
-        const hipError_t res = check_resident(dopri5_bwd_kernel<D, HUTCH>, kThreads, grid);
+        const hipError_t res = a.nreg ? check_resident(dopri5_bwd_kernel<D, HUTCH, true>, kThreads, grid)
+                                      : check_resident(dopri5_bwd_kernel<D, HUTCH, false>, kThreads, grid);
         if (res != hipSuccess) return res;
     }
-    hipLaunchKernelGGL((dopri5_bwd_kernel<D, HUTCH>), dim3(grid), dim3(kThreads), 0, s, a);
+    dbg_timing_begin(s);
+    if (a.nreg) hipLaunchKernelGGL((dopri5_bwd_kernel<D, HUTCH, true>), dim3(grid), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((dopri5_bwd_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
     dbg_timing_end(s);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;

@@ -671,6 +671,88 @@ __device__ __forceinline__ double next_step_size(double dt, float worst) {
 // python's max(a, b) over a 2-tuple: keeps `a` unless b > a (so a NaN in `a` sticks, one in `b` is ignored)
 __device__ __forceinline__ float pymax(float a, float b) { return b > a ? b : a; }
 
+// ---- regularised dynamics (include/cnf_hip.h, CnfRegDesc) ---------------------------------------------------------------
+// integrand of regulariser `kind` for one row's dz/dt: l1 = mean_i |dx_i|, l2 = ||dx||_2 / sqrt(d)
+template <int D>
+__device__ __forceinline__ float reg_integrand(int kind, const float (&dx)[D]) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        s1 += fabsf(dx[m]);
+        s2 = fmaf(dx[m], dx[m], s2);
+    }
+    return kind == CNF_REG_L1 ? s1 / (float)D : sqrtf(s2) / sqrtf((float)D);
+}
+// c[k] * d integrand_k / d dx, summed over the regularisers (autograd's conventions: |x|' = sign(x) with sign(0) = 0,
+// ||x||' = x / ||x|| with 0 at the origin)
+template <int D>
+__device__ __forceinline__ void reg_cotangent(int nreg, const int (&kind)[CNF_MAX_REG], const float (&c)[CNF_MAX_REG],
+                                              const float (&dx)[D], float (&out)[D]) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        s2 = fmaf(dx[m], dx[m], s2);
+        out[m] = 0.f;
+    }
+    const float nrm = sqrtf(s2);
+    const float inv = nrm > 0.f ? 1.0f / (nrm * sqrtf((float)D)) : 0.f;
+#pragma unroll
+    for (int k = 0; k < CNF_MAX_REG; ++k) {
+        if (k >= nreg) break;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const float sg = dx[m] > 0.f ? 1.f : (dx[m] < 0.f ? -1.f : 0.f);
+            out[m] += kind[k] == CNF_REG_L1 ? c[k] * (sg / (float)D) : c[k] * (dx[m] * inv);
+        }
+    }
+}
+// The first-step heuristic (Appendix B.2) over (z, logp, r_1 .. r_nreg): python's max() walks the tensors in the order of
+// the state tuple.  nreg = 0: initial_h0 / initial_dt below with all = false.
+__device__ __forceinline__ float initial_h0_reg(float d0z, float d0l, float d1z, float d1l, int nreg,
+                                                const float (&d0r)[CNF_MAX_REG], const float (&d1r)[CNF_MAX_REG]) {
+    float m0 = pymax(d0z, d0l), m1 = pymax(d1z, d1l), mr = pymax(d0z / d1z, d0l / d1l);
+#pragma unroll
+    for (int k = 0; k < CNF_MAX_REG; ++k) {
+        if (k >= nreg) break;
+        m0 = pymax(m0, d0r[k]);
+        m1 = pymax(m1, d1r[k]);
+        mr = pymax(mr, d0r[k] / d1r[k]);
+    }
+    return (m0 < 1e-5f || m1 < 1e-5f) ? 1e-6f : 0.01f * mr;
+}
+__device__ __forceinline__ float initial_dt_reg(float h0, float d1z, float d1l, float d2z, float d2l, int nreg,
+                                                const float (&d1r)[CNF_MAX_REG], const float (&d2r)[CNF_MAX_REG]) {
+    float m1 = pymax(d1z, d1l), m2 = pymax(d2z, d2l);
+#pragma unroll
+    for (int k = 0; k < CNF_MAX_REG; ++k) {
+        if (k >= nreg) break;
+        m1 = pymax(m1, d1r[k]);
+        m2 = pymax(m2, d2r[k]);
+    }
+    float mm = pymax(pymax(m1, d2z), d2l);   // max(d1 + d2): the concatenated tuple, d1's first
+#pragma unroll
+    for (int k = 0; k < CNF_MAX_REG; ++k) {
+        if (k >= nreg) break;
+        mm = pymax(mm, d2r[k]);
+    }
+    const float h1 = (m1 <= 1e-15f && m2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / mm, 0.2f);
+    return fminf(100.f * h0, h1);
+}
+// dopri5's quartic through one component of an accepted step, at x in [0, 1] (B.6): u, v = the step's ends, k = its slopes
+__device__ __forceinline__ float dense_quartic(float dtf, float x, float u, float v, const float (&k)[7]) {
+    float mid = 0.f;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) mid += (dtf * kCMid[s]) * k[s];
+    mid = u + mid;
+    const float f0 = k[0], f1 = k[6];
+    const float ca = (-2 * dtf) * f0 + (2 * dtf) * f1 + -8 * u + -8 * v + 16 * mid;
+    const float cb = (5 * dtf) * f0 + (-3 * dtf) * f1 + 18 * u + 14 * v + -32 * mid;
+    const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
+    const float cd = dtf * f0;
+    const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+    return ca * x4 + cb * x3 + cc * x2 + cd * x + u;
+}
+
 // ---- CNF_FLAG_ADJ_CONTROL_ALL: which tensors of the adjoint state the step controller looks at ------------------------
 // The reference hands odeint_adjoint tolerance LISTS of length 2, and torchdiffeq 0.0.1 zips tolerances with the state
 // tuple: in the backward solve only (z, logp) drive the error ratios (recalled, unverifiable

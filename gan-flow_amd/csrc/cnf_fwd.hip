@@ -191,6 +191,8 @@ __global__ __launch_bounds__(NW * 64)
     __shared__ typename std::conditional<B16, NetLdsB16<D>, NetLds<D>>::type net;
     __shared__ WaveLds<D> wl[NW];
     __shared__ RedLds red;
+    // regularised dynamics (cnf_solve_fwd_reg; batch-global solves only): slopes of every row's regulariser integrals
+    __shared__ float krs[GLOBAL ? NW : 1][7][CNF_MAX_REG][kRows];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     constexpr int C = D + 1;
     if (tid == 0) red.status = 0;
@@ -200,6 +202,8 @@ __global__ __launch_bounds__(NW * 64)
         stage_net(net, a.params, tid, NW * 64);
     }
     zero_slopes(wl, NW, tid, NW * 64);
+    if constexpr (GLOBAL)
+        for (int idx = tid; idx < NW * 7 * CNF_MAX_REG * kRows; idx += NW * 64) (&krs[0][0][0][0])[idx] = 0.f;   // as zero_slopes
     __syncthreads();
     const long base = ((long)blockIdx.x * NW + w) * kRows;
     if (!GLOBAL && base >= a.rows) return;
@@ -239,6 +243,15 @@ __global__ __launch_bounds__(NW * 64)
     int nfe = 0, nacc = 0, nrej = 0, status = 0;
     float h0 = 0.f, d1z = 0.f, d1l = 0.f;
     float sc[C];  // initial-step scale, atol + |y0| * rtol
+
+    // Regularised dynamics: every row integrates its regularisers' integrands with the steps' own weights -- the state the
+    // reference integrates is their batch mean, and the integral is linear in the integrand, so the mean is taken once,
+    // after the solve (reg_mean_kernel).  With tolerances of 1e20 these states never fail the accept test; what their batch
+    // means DO steer is the first step (the heuristic uses rtol[0] / atol[0] for every tensor): one more grid sum in each of
+    // its two halves.
+    const int nreg = GLOBAL ? a.nreg : 0;
+    float r0[CNF_MAX_REG] = {0.f, 0.f}, r1[CNF_MAX_REG] = {0.f, 0.f};
+    float d1r[CNF_MAX_REG] = {0.f, 0.f}, kr_f0[CNF_MAX_REG] = {0.f, 0.f};
 
     // Several output times (cnf_solve_fwd_times; torchdiffeq's odeint(func, y0, t) with len(t) > 2): ONE adaptive
     // integration whose steps ignore the output times; every times[i] is read off the quartic of the accepted step that
@@ -290,6 +303,12 @@ __global__ __launch_bounds__(NW * 64)
 #pragma unroll
         for (int m = 0; m < D; ++m) k[m] = sgn * f[m];
         k[D] = -sgn * div;
+        float kr[CNF_MAX_REG] = {0.f, 0.f};   // slopes of this row's regulariser integrals (the solver's time runs with sgn)
+        if (GLOBAL && nreg) {
+#pragma unroll
+            for (int q_ = 0; q_ < CNF_MAX_REG; ++q_)
+                if (q_ < nreg) kr[q_] = sgn * reg_integrand<D>(a.reg_kind[q_], f);
+        }
 
         if (phase == PH_F0) {
             // ---- f0 and the first half of the initial-step heuristic (B.2)
@@ -312,7 +331,20 @@ __global__ __launch_bounds__(NW * 64)
             const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
             d1z = (float)sqrt(S[2] / nz);
             d1l = (float)sqrt(S[3] / nl);
-            if (pymax(d0z, d0l) < 1e-5f || pymax(d1z, d1l) < 1e-5f) {
+            if (GLOBAL && nreg) {
+                double S2[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) {
+                    krs[w][0][q_][j] = kr[q_];
+                    kr_f0[q_] = kr[q_];
+                    if (counted) S2[q_] = (double)kr[q_];
+                }
+                if (!wg_allreduce4(gs, red, S2, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
+                const float d0r[CNF_MAX_REG] = {0.f, 0.f};   // the states start at 0: scale = atol
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) d1r[q_] = fabsf((float)(S2[q_] / nl) / atol);
+                h0 = initial_h0_reg(d0z, d0l, d1z, d1l, nreg, d0r, d1r);
+            } else if (pymax(d0z, d0l) < 1e-5f || pymax(d1z, d1l) < 1e-5f) {
                 h0 = 1e-6f;
             } else {
                 h0 = 0.01f * pymax(d0z / d1z, d0l / d1l);
@@ -331,28 +363,54 @@ __global__ __launch_bounds__(NW * 64)
                 const float u = (k[c] - ws.kst[0][c][j]) / sc[c];
                 if (counted) S[c < D ? 0 : 1] += (double)u * u;
             }
+            if (GLOBAL && nreg && counted) {   // the change of the regularisers' batch means: the two free slots of this sum
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) S[2 + q_] = (double)(kr[q_] - kr_f0[q_]);
+            }
             if (GLOBAL) {
                 if (!wg_allreduce4(gs, red, S, w, lane)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             } else {
                 wave_allreduce4(S);
             }
             const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
-            float h1;
-            if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
-                h1 = fmaxf(1e-6f, h0 * 1e-3f);
+            if (GLOBAL && nreg) {
+                float d2r[CNF_MAX_REG];
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) d2r[q_] = fabsf((float)(S[2 + q_] / nl) / atol) / h0;
+                dt = (double)initial_dt_reg(h0, d1z, d1l, d2z, d2l, nreg, d1r, d2r);
             } else {
-                h1 = powf(0.01f / pymax(pymax(pymax(d1z, d1l), d2z), d2l), 0.2f);
+                float h1;
+                if (pymax(d1z, d1l) <= 1e-15f && pymax(d2z, d2l) <= 1e-15f) {
+                    h1 = fmaxf(1e-6f, h0 * 1e-3f);
+                } else {
+                    h1 = powf(0.01f / pymax(pymax(pymax(d1z, d1l), d2z), d2l), 0.2f);
+                }
+                dt = (double)fminf(100.f * h0, h1);
             }
-            dt = (double)fminf(100.f * h0, h1);
             restart = true;
         } else {
             // ---- a Runge-Kutta stage finished: k is slope number stage+1
 #pragma unroll
             for (int c = 0; c < C; ++c) ws.kst[stage][c][j] = k[c];
+            if (GLOBAL && nreg) {
+#pragma unroll
+                for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) krs[w][stage][q_][j] = kr[q_];
+            }
             if (stage < 6) {
                 ++stage;
             } else {
                 // all seven slopes known: yi is the candidate y1, k its slope (FSAL)
+                if (GLOBAL && nreg) {   // the regularisers' candidate: the sixth stage point, like every other component
+                    float al6, b6[6];
+                    stage_coeffs(6, al6, b6);
+#pragma unroll
+                    for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int s = 0; s < 6; ++s) acc += (dtf * b6[s]) * krs[w][s][q_][j];
+                        r1[q_] = r0[q_] + acc;
+                    }
+                }
                 double S[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -394,6 +452,13 @@ __global__ __launch_bounds__(NW * 64)
                         y0[c] = y1[c];
                         ws.kst[0][c][j] = k[c];
                     }
+                    if (GLOBAL && nreg) {
+#pragma unroll
+                        for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) {
+                            r0[q_] = r1[q_];
+                            krs[w][0][q_][j] = kr[q_];
+                        }
+                    }
                     tau = tau + dt;
                 } else {
                     ++nrej;
@@ -433,6 +498,18 @@ __global__ __launch_bounds__(NW * 64)
 #pragma unroll
             for (int m = 0; m < D; ++m) a.z_out[last * slab_z + row * D + m] = yo[m];
             a.logp_out[last * slab_l + row] = yo[D];
+        }
+        if (GLOBAL && nreg) {   // this row's regulariser integrals at the end time, off the same quartic
+            const float ta = (float)tau, tb = (float)(tau + dt);
+            const float x = ((float)tau_end - ta) / (tb - ta);
+#pragma unroll
+            for (int q_ = 0; q_ < CNF_MAX_REG; ++q_) {
+                float ks_[7];
+#pragma unroll
+                for (int s = 0; s < 7; ++s) ks_[s] = krs[w][s][q_][j];
+                const float v = dense_quartic(dtf, x, r0[q_], r1[q_], ks_);
+                if (counted && q_ < nreg) a.reg_rows[(long)q_ * a.rows + row] = v;
+            }
         }
     }
     if (lane == 0 && (!GLOBAL || (blockIdx.x == 0 && w == 0) || status != 0)) {
@@ -490,6 +567,26 @@ static hipError_t launch_solve_t(const SolveArgs& a, int solver, bool global, hi
         hipLaunchKernelGGL((dopri5_kernel<D, HUTCH, false, NW, B16>), dim3(g), dim3(NW * 64), 0, s, a);
     }
     dbg_timing_end(s);
+    return hipGetLastError();
+}
+
+// batch means of the per-row regulariser integrals (dopri5_kernel, a.reg_rows): one workgroup per regulariser, a fixed
+// summation order (deterministic), double accumulation
+__global__ __launch_bounds__(256) void reg_mean_kernel(const float* __restrict__ reg_rows, long rows, float* __restrict__ out) {
+    __shared__ double part[256];
+    const float* src = reg_rows + (size_t)blockIdx.x * rows;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < rows; i += 256) s += (double)src[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) part[threadIdx.x] += part[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(part[0] / (double)rows);
+}
+hipError_t launch_reg_mean(const float* reg_rows, long rows, int nreg, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reg_mean_kernel, dim3(nreg), dim3(256), 0, s, reg_rows, rows, out);
     return hipGetLastError();
 }
 

@@ -45,6 +45,12 @@ struct SolveArgs {
     // logp_out (slab 0 = the input; t0 = times[0], t1 = times[n_times - 1]); 0 = the ordinary solve
     int n_times;
     float times[kMaxTimes];
+    // regularised dynamics (cnf_solve_fwd_reg / cnf_solve_bwd_reg; dopri5_kernel<.., GLOBAL> and dopri5_bwd_kernel): nreg = 0 off
+    int nreg;
+    int reg_kind[CNF_MAX_REG];   // CNF_REG_L1 | CNF_REG_L2
+    float* reg_rows;             // forward: every row's integral of its regularisers' integrands, [nreg][rows]
+    const float* reg_val;        // adjoint: the regularisation states at t1 (device, nreg floats)
+    const float* reg_cot;        // adjoint: dL/d(state) (device, nreg floats)
 };
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,

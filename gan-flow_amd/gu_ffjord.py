@@ -18,14 +18,15 @@ from .util import count_parameters, get_logger, makedirs, w_distance
 
 def build_model(dim=2, dims=(64, 64, 64), num_blocks=1, time_length=0.5, train_T=True, divergence_fn="brute_force",
                 solver="dopri5", atol=1e-5, rtol=1e-5, rademacher=False, layer_type="concatsquash", residual=False,
-                batch_norm=False, bn_lag=0.0, nonlinearity="tanh"):
+                batch_norm=False, bn_lag=0.0, nonlinearity="tanh", regularization_fns=()):
     """`num_blocks` CNF blocks over a dim -> dims -> dim concatsquash/tanh ODEnet: the architecture stored in the
     reference's checkpoints.  Other `layer_type`s: see ODEnet."""
     blocks = []
     for _ in range(num_blocks):
         net = ODEnet(tuple(dims), (dim,), strides=None, conv=False, layer_type=layer_type, nonlinearity=nonlinearity)
         fn = ODEfunc(net, divergence_fn=divergence_fn, residual=residual, rademacher=rademacher)
-        blocks.append(CNF(fn, T=time_length, train_T=train_T, regularization_fns=(), solver=solver, atol=atol, rtol=rtol))
+        blocks.append(CNF(fn, T=time_length, train_T=train_T, regularization_fns=tuple(regularization_fns), solver=solver, atol=atol,
+                          rtol=rtol))
     if batch_norm:   # build_model_tabular's arrangement: a norm layer first, then one after every CNF block
         chain = [MovingBatchNorm1d(dim, bn_lag=bn_lag)]
         for blk in blocks:

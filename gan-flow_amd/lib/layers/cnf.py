@@ -73,6 +73,31 @@ class _SolveTimes(torch.autograd.Function):
         return a_z, a_l, g_theta, None, None, None, None, None
 
 
+class _SolveReg(torch.autograd.Function):
+    """The regularised solve: (z0, logp0, theta) -> (z1, logp1, regularisation states[n]); backward = cnf_solve_bwd_reg."""
+
+    @staticmethod
+    def forward(ctx, z, logp, flat_params, block, t0, t1, opts, net, e, reg):
+        z1, logp1, regs, stats = _native.solve_fwd_reg(net, reg, flat_params.detach(), z.detach(), logp.detach(), t0, t1, opts, e)
+        block._after_solve(stats, backward=False)
+        ctx.block, ctx.t0, ctx.t1, ctx.opts, ctx.net, ctx.reg = block, t0, t1, opts, net, reg
+        ctx.fwd_stats = stats
+        ctx.save_for_backward(z1, logp1, regs, flat_params.detach(), e if e is not None else z.new_zeros(0))
+        return z1, logp1, regs
+
+    @staticmethod
+    def backward(ctx, grad_z, grad_logp, grad_regs):
+        z1, logp1, regs, flat_params, e = ctx.saved_tensors
+        e = e if e.numel() else None
+        grad_z = torch.zeros_like(z1) if grad_z is None else grad_z
+        grad_logp = torch.zeros_like(logp1) if grad_logp is None else grad_logp
+        grad_regs = torch.zeros_like(regs) if grad_regs is None else grad_regs
+        gx, gl, gp, stats = _native.solve_bwd_reg(ctx.net, ctx.reg, flat_params, z1, logp1, regs, grad_z, grad_logp, grad_regs,
+                                                  ctx.t0, ctx.t1, _native.with_after(ctx.opts, ctx.fwd_stats), e)
+        ctx.block._after_solve(stats, backward=True)
+        return gx, gl, gp, None, None, None, None, None, None, None
+
+
 class CNF(nn.Module):
     def __init__(self, odefunc, T=1.0, train_T=False, regularization_fns=None, solver="dopri5", atol=1e-5, rtol=1e-5):
         super().__init__()
@@ -165,9 +190,15 @@ class CNF(nn.Module):
             if reverse:
                 times = times[::-1]   # _flip(integration_times, 0)
             z_t, logpz_t = _SolveTimes.apply(z, _logpz, flat, self, times, opts, net, e)
+            self.regularization_states = ()
+        elif self.training and self.nreg > 0:
+            # the reference integrates the regularisers' states in training mode only (its test branch passes two states)
+            reg = _native.reg_desc(self.odefunc.reg_kinds)
+            z_t, logpz_t, regs = _SolveReg.apply(z, _logpz, flat, self, t0, t1, opts, net, e, reg)
+            self.regularization_states = tuple(regs[i] for i in range(self.nreg))
         else:
             z_t, logpz_t = _Solve.apply(z, _logpz, flat, self, t0, t1, opts, net, e)
-        self.regularization_states = ()
+            self.regularization_states = ()
         return (z_t, logpz_t) if logpz is not None else z_t
 
     def _end_time(self):

@@ -191,6 +191,36 @@ int cnf_solve_fwd_times(const CnfNetDesc *net, const float *params, const float 
                         float *z_out, float *logp_out, void *workspace, size_t workspace_bytes,
                         CnfStats *stats, void *stream);
 
+/* Regularised dynamics: RegularizedODEfunc with non-empty regularization_fns (ffjord/lib/layers/wrappers/
+ * cnf_regularization.py, un-vendored submodule /root/reference/.gitmodules:4-6; the wrapper class every reference
+ * checkpoint carries).  Each regulariser is one more state of the ODE, d r / dt = reg_fn(dz/dt) averaged over the batch,
+ * started at 0; CNF.forward integrates it with tolerances 1e20 (it never fails the accept test) -- but the solver's
+ * first-step heuristic takes rtol[0] / atol[0] for EVERY state tensor, so the regularisers do steer the first step of
+ * both solves, and the kernels reproduce that (parity unpinned: no reference artefact records such a run).
+ *   CNF_REG_L1: l1_regularzation_fn, mean over the batch of mean_i |dz_i/dt|
+ *   CNF_REG_L2: l2_regularzation_fn, mean over the batch of ||dz/dt||_2 / sqrt(dim)
+ * cnf_solve_fwd_reg = cnf_solve_fwd + reg_out[n] (device): the regularisation states at t1.
+ * cnf_solve_bwd_reg = cnf_solve_bwd + reg_t1[n] (device: those states, they scale the first backward step) and
+ *   grad_reg[n] (device: dL/d(state)); the adjoint of a regulariser state is constant, and enters the sweep as
+ *   grad_reg / rows * d reg_fn / d(dz/dt) added to the cotangent of dz/dt.
+ * dopri5 with batch-global step control, hidden width 64, dim 1 | 2, up to 16 384 rows (the one-tile-per-wave kernels of
+ * csrc/cnf_fwd.hip / cnf_bwd.hip); kinds: up to CNF_MAX_REG entries, in the order of the reference's regularization_fns. */
+enum { CNF_REG_L1 = 1, CNF_REG_L2 = 2 };
+#define CNF_MAX_REG 2
+typedef struct CnfRegDesc {
+    int32_t n;                     /* 1 .. CNF_MAX_REG */
+    int32_t kind[CNF_MAX_REG];
+} CnfRegDesc;
+int cnf_solve_fwd_reg(const CnfNetDesc *net, const CnfRegDesc *reg, const float *params, const float *x, const float *logp0,
+                      const float *e, int64_t rows, float t0, float t1, const CnfSolverOpts *opts,
+                      float *z_out, float *logp_out, float *reg_out, void *workspace, size_t workspace_bytes,
+                      CnfStats *stats, void *stream);
+int cnf_solve_bwd_reg(const CnfNetDesc *net, const CnfRegDesc *reg, const float *params, const float *z1, const float *logp1,
+                      const float *e, const float *reg_t1, const float *grad_z1, const float *grad_logp1,
+                      const float *grad_reg, int64_t rows, float t0, float t1, const CnfSolverOpts *opts,
+                      float *grad_x, float *grad_logp0, float *grad_params, void *workspace, size_t workspace_bytes,
+                      CnfStats *stats, void *stream);
+
 /* One evaluation of the adjoint's augmented dynamics (the closure `augmented_dynamics` inside
  * OdeintAdjointMethod.backward, a10): given z, a_z, a_logp returns
  *   f, -div, vjp_z = -(a_z . df/dz) + a_logp * d(div)/dz   (rows x dim)

@@ -27,4 +27,5 @@ from .odeint import odeint, odeint_adjoint, SOLVERS  # noqa: F401
 from .layers import (  # noqa: F401
     ConcatSquashLinear, ODEnet, ODEfunc, RegularizedODEfunc, CNF, SequentialFlow,
     divergence_bf, divergence_approx, get_transforms, build_cnf, standard_normal_logprob,
+    l1_regularzation_fn, l2_regularzation_fn,
 )

@@ -155,6 +155,24 @@ class ODEfunc(nn.Module):
         return (dy, -div) + tuple(torch.zeros_like(s).requires_grad_(True) for s in states[2:])
 
 
+# The kinetic regularisers of ffjord/lib/layers/wrappers/cnf_regularization.py (un-vendored submodule; restated as recalled,
+# original spelling of the names kept): each returns ONE scalar per evaluation, the batch mean of a function of dx = dz/dt,
+# which RegularizedODEfunc appends to the dynamics as the slope of one more state.
+def _batch_root_mean_squared(tensor):
+    tensor = tensor.view(tensor.shape[0], -1)
+    return torch.mean(torch.norm(tensor, p=2, dim=1) / tensor.shape[1] ** 0.5)
+
+
+def l1_regularzation_fn(x, logp, dx, dlogp, unused_context):
+    del x, logp, dlogp
+    return torch.mean(torch.abs(dx))
+
+
+def l2_regularzation_fn(x, logp, dx, dlogp, unused_context):
+    del x, logp, dlogp
+    return _batch_root_mean_squared(dx)
+
+
 class RegularizedODEfunc(nn.Module):
     """Wrapper present in the checkpoints even with zero regularisers: a pass-through then (a6)."""
 
@@ -233,6 +251,11 @@ class CNF(nn.Module):
         self.regularization_states = state_t[2:]
         return (z_t, logpz_t) if logpz is not None else z_t
 
+    def get_regularization_states(self):
+        reg_states = self.regularization_states
+        self.regularization_states = None
+        return reg_states
+
     def num_evals(self):
         return self.odefunc._num_evals.item()
 
@@ -274,12 +297,12 @@ def standard_normal_logprob(z):
 
 def build_cnf(dim, hidden_dims=(64, 64, 64), num_blocks=1, T=0.5, train_T=True, divergence_fn="brute_force",
               solver="dopri5", atol=1e-5, rtol=1e-5, nonlinearity="tanh", rademacher=False, residual=False,
-              layer_type="concatsquash"):
+              layer_type="concatsquash", regularization_fns=()):
     """The model the reference's checkpoints hold: `num_blocks` CNF blocks, concatsquash/tanh ODEnet."""
     blocks = []
     for _ in range(num_blocks):
         net = ODEnet(tuple(hidden_dims), (dim,), strides=None, conv=False, layer_type=layer_type,
                      nonlinearity=nonlinearity)
         fn = ODEfunc(net, divergence_fn=divergence_fn, residual=residual, rademacher=rademacher)
-        blocks.append(CNF(fn, T=T, train_T=train_T, regularization_fns=(), solver=solver, atol=atol, rtol=rtol))
+        blocks.append(CNF(fn, T=T, train_T=train_T, regularization_fns=tuple(regularization_fns), solver=solver, atol=atol, rtol=rtol))
     return SequentialFlow(blocks)

@@ -219,3 +219,73 @@ def test_adjoint_error_control_modes():
     d1 = max(rms(-f.detach(), z1), rms(-nd.detach(), dl1), rms(-vz, a_z))   # reversed time: slopes change sign
     assert abs(stats["rows"]["dts"][0] - (0.01 / d1) ** 0.2) < 1e-5 * stats["rows"]["dts"][0]
     assert stats["rows"]["dts"][0] != stats["state_only"]["dts"][0]
+
+
+def test_regularised_dynamics_oracle_is_self_consistent():
+    """RegularizedODEfunc with the l1 / l2 kinetic regularisers (oracle.l1_regularzation_fn / l2_regularzation_fn, restated as
+    recalled; parity unpinned): the regularisation states are integrals of batch means, and odeint_adjoint carries their
+    constant adjoints.  float64, tolerances 1e-12: (i) the states equal a fine quadrature of the integrands along the
+    solution; (ii) d loss / d x from the adjoint equals central finite differences to 1e-3 (1e-8 on most rows, 2e-4 on a row
+    that crosses a kink); (iii) d loss / d theta agrees with backprop through the same solve to a few 1e-3 -- a_z and a_theta are not under error control (the tolerance lists cover
+    (z, logp, r) only) and the regularisers' integrands have kinks, so the adjoint's quadrature is only as good as the steps
+    the smooth state needed (without regularisers the same comparison gives 1e-8)."""
+    from _helpers import oracle_random_model
+    fns = (oracle.l1_regularzation_fn, oracle.l2_regularzation_fn)
+    m = oracle_random_model(2, seed=3, scale=1.5, regularization_fns=fns).double()
+    m.train()
+    x = torch.randn(32, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    blk = m.chain[0]
+    blk.rtol = blk.atol = 1e-12
+    T = float(blk.sqrt_end_time.detach() ** 2)
+    zero = torch.zeros(32, 1, dtype=torch.float64)
+
+    def loss_of(xv):
+        z, dl = m(xv, zero)
+        r = blk.get_regularization_states()
+        return -(oracle.standard_normal_logprob(z).sum(1, keepdim=True) - dl).mean() + 0.3 * r[0] + 0.7 * r[1], r
+
+    m.zero_grad()
+    xx = x.clone().requires_grad_(True)
+    loss, regs = loss_of(xx)
+    loss.backward()
+    params = list(blk.odefunc.odefunc.diffeq.parameters())
+    g_adj = [p.grad.clone() for p in params]
+    # (i) quadrature of the integrands along a fine rk4 solution
+    fn = blk.odefunc.odefunc
+    n = 400
+    h = T / n
+    z = x.clone()
+    acc = torch.zeros(2, dtype=torch.float64)
+    with torch.no_grad():
+        def field(t, zz):
+            with torch.enable_grad():
+                return fn(torch.tensor(t, dtype=torch.float64), (zz.clone(), zero))[0].detach()
+        def integrands(dx):
+            return torch.stack([dx.abs().mean(), (dx.norm(dim=1) / 2 ** 0.5).mean()])
+        for i in range(n):
+            t = i * h
+            k1 = field(t, z); k2 = field(t + h / 2, z + h / 2 * k1); k3 = field(t + h / 2, z + h / 2 * k2); k4 = field(t + h, z + h * k3)
+            zn = z + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+            acc += h / 6 * (integrands(k1) + 4 * integrands(field(t + h / 2, (z + zn) / 2 + h / 8 * (k1 - k4))) + integrands(k4))
+            z = zn
+    assert abs(float(regs[0]) - acc[0].item()) < 1e-6 and abs(float(regs[1]) - acc[1].item()) < 1e-6
+    # (ii) finite differences in x
+    eps = 1e-4
+    with torch.no_grad():
+        for (i, j) in ((0, 0), (7, 1)):
+            xp, xm = x.clone(), x.clone()
+            xp[i, j] += eps
+            xm[i, j] -= eps
+            fd = (loss_of(xp)[0] - loss_of(xm)[0]).item() / (2 * eps)
+            assert abs(fd - xx.grad[i, j].item()) < 1e-3 * abs(fd), (i, j, fd, xx.grad[i, j].item())
+    # (iii) backprop through the same adaptive solve
+    m.zero_grad()
+    blk.odefunc.before_odeint()
+    st = oracle.odeint(blk.odefunc, (x, zero, torch.tensor(0.0, dtype=torch.float64), torch.tensor(0.0, dtype=torch.float64)),
+                       torch.tensor([0.0, T], dtype=torch.float64), rtol=[1e-12, 1e-12, 1e20, 1e20], atol=[1e-12, 1e-12, 1e20, 1e20],
+                       method="dopri5")
+    l2 = -(oracle.standard_normal_logprob(st[0][1]).sum(1, keepdim=True) - st[1][1]).mean() + 0.3 * st[2][1] + 0.7 * st[3][1]
+    assert abs(l2.item() - loss.item()) < 1e-7
+    l2.backward()
+    for p, ga in zip(params, g_adj):
+        assert (p.grad - ga).abs().max() < 1e-2 * p.grad.abs().max()
