@@ -453,6 +453,12 @@ namespace cnf {
 #define CNF_WIDE_BWD_BF16 1
 #endif
 constexpr bool kWideBwdB16 = CNF_WIDE_BWD_BF16 != 0;
+// the fixed-grid adjoint: factors + fold on the matrix cores like the dopri5 kernel (1), or result blocks per stage and the
+// slot fold (0)
+#ifndef CNF_WIDE_FIXED_FACT
+#define CNF_WIDE_FIXED_FACT 1
+#endif
+constexpr bool kWideFixedFact = kWideBwdB16 && CNF_WIDE_FIXED_FACT != 0;
 // head of the adjoint's workspace, in floats: W^T of the two matrices in fp32, or the pieces of W and W^T
 constexpr size_t kWideBwdHeadFloats = kWideBwdB16 ? 2 * kWideSetBytes / sizeof(float) : (size_t)2 * kWH * kWH;
 
@@ -938,7 +944,7 @@ __global__ __launch_bounds__(kThreads) void wide_fixed_bwd_kernel(SolveArgs a, c
             else wq = (st == 0 || st == 3) ? dt / 8 : 3 * (dt / 8);
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) wts[s_] = st == s_ ? wq : wts[s_];
-            aug_eval_sh<D, HUTCH, kWideBwdB16>(sh, a.params, wt, lane, w, sgn * ti, zz, ee, az, al, sgn, wq != 0.f, f, div, vz,
+            aug_eval_sh<D, HUTCH, kWideFixedFact>(sh, a.params, wt, lane, w, sgn * ti, zz, ee, az, al, sgn, wq != 0.f, f, div, vz,
                                   region + (size_t)st * kWideSlotF<D>, 0);
 #pragma unroll
             for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
@@ -983,7 +989,7 @@ __global__ __launch_bounds__(kThreads) void wide_fixed_bwd_kernel(SolveArgs a, c
             }
         }
         const int sl[7] = {0, 1, 2, 3, 4, 5, 6};
-        wide_commit<D, NS, kWideBwdB16>(region, sl, wts, step == 0, tid, 0, sh.fold_area());   // slots with weight zero are not read
+        wide_commit<D, NS, kWideFixedFact>(region, sl, wts, step == 0, tid, 0, sh.fold_area());   // slots with weight zero are not read
     }
     if (status == 0 && counted) {
 #pragma unroll

@@ -33,3 +33,12 @@ F = 790528
 print("H=256 B=%d scale %.1f | fwd %.3f ms nfe %d  %.1f us/eval  %.1f TFLOP/s | bwd %.3f ms nfe %d steps %d+%d  %.1f us/eval  %.1f TFLOP/s"
       % (B, scale, tf, sf.nfe, 1e3 * tf / sf.nfe, B * sf.nfe * F / tf / 1e9, tb, sb.nfe, sb.n_accepted, sb.n_rejected,
          1e3 * tb / sb.evals_run, 3 * B * sb.nfe * F / tb / 1e9))
+
+# fixed-grid adjoint (rk4, 5 steps) at the same width
+ro = nat.make_opts("rk4", 1e-5, 1e-5, 0.1)
+z1, l1, sf = nat.solve_fwd(net, params, x, None, 0.0, T, ro)
+for rep in range(3):
+    _, _, _, sb = nat.solve_bwd(net, params, z1, l1, z1 / B, torch.full_like(l1, 1.0 / B), 0.0, T, ro)
+    tb = nat.last_kernel_ms()
+sb = nat.Stats(sb)
+print("H=256 rk4 adjoint: %.3f ms, %d evaluations, %.1f us/eval" % (tb, sb.evals_run, 1e3 * tb / sb.evals_run))
