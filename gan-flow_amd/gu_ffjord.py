@@ -59,6 +59,20 @@ def compute_loss(model, x):
     return -torch.mean(logpz - delta_logp)
 
 
+def get_regularization(model, coeffs):
+    """Sum over the CNF blocks of their regularisation states, weighted: what ffjord/train_misc.py adds to the loss
+    (`--l1int` / `--l2int`).  Reads (and clears) the states the last training-mode forward left in the blocks."""
+    total = None
+    for block in model.chain:
+        if isinstance(block, CNF) and block.nreg:
+            states = block.get_regularization_states()
+            if len(states) != len(coeffs):
+                raise ValueError("%d regularisation states, %d coefficients" % (len(states), len(coeffs)))
+            part = sum(c * s for c, s in zip(coeffs, states))
+            total = part if total is None else total + part
+    return total
+
+
 def count_nfe(model):
     return sum(block.num_evals() for block in model.chain if hasattr(block, "num_evals"))
 
@@ -466,6 +480,9 @@ def parse_args(argv=None):
     p.add_argument("--adjoint_error_control", type=str, default="state_only", choices=["state_only", "all"],
                    help="which tensors of the adjoint state steer the backward solve: (z, logp) as the reference's length-2 "
                         "tolerance lists do (default), or the per-row adjoints as well (CNF_FLAG_ADJ_CONTROL_ALL; not in the reference)")
+    p.add_argument("--l1int", type=float, default=None, help="coefficient of the l1 kinetic regulariser (ffjord/train_misc.py's "
+                   "flag: integral of the batch mean of mean_i |dz_i/dt|); trains through the autograd loop")
+    p.add_argument("--l2int", type=float, default=None, help="coefficient of the l2 kinetic regulariser (||dz/dt|| / sqrt(d))")
     p.add_argument("--eval_size", type=int, default=100000)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--save", type=str, default="experiments/gu_ffjord")
@@ -494,11 +511,23 @@ def main(argv=None):
     logger.info(str(args))
     data = make_gu(args.gu_num, device="cpu", seed=args.seed, extend_dim=True)
     torch.manual_seed(args.seed)
+    from .lib.layers.wrappers.cnf_regularization import l1_regularzation_fn, l2_regularzation_fn
+    reg_fns, reg_coeffs = [], []   # in the order of the original's REGULARIZATION_FNS table
+    for coeff, fn in ((args.l1int, l1_regularzation_fn), (args.l2int, l2_regularzation_fn)):
+        if coeff is not None:
+            reg_fns.append(fn)
+            reg_coeffs.append(coeff)
     model = build_model(2, tuple(int(d) for d in args.dims.split("-")), args.num_blocks, args.time_length, args.train_T,
                         args.divergence_fn, args.solver, args.atol, args.rtol, layer_type=args.layer_type,
                         residual=args.residual, batch_norm=args.batch_norm, bn_lag=args.bn_lag,
-                        nonlinearity=args.nonlinearity).to(device)
+                        nonlinearity=args.nonlinearity, regularization_fns=tuple(reg_fns)).to(device)
     odenets = [blk.odefunc.odefunc.diffeq for blk in model.chain if isinstance(blk, CNF)]
+    if reg_fns:
+        if args.solver != "dopri5" or args.dims != "64-64-64" or args.adjoint_error_control != "state_only":
+            raise SystemExit("--l1int / --l2int: built for dopri5, --dims 64-64-64 and the default adjoint error control")
+        if args.fused or args.graphed:
+            logger.info("regularised dynamics train through the eager autograd + torch.optim.Adam loop")
+        args.fused = args.graphed = 0
     if args.fused and (args.layer_type != "concatsquash" or args.batch_norm or any(n.is_padded() for n in odenets)
                        or args.solver != "dopri5"):
         logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of concatsquash CNF blocks of hidden "
@@ -582,6 +611,8 @@ def main(argv=None):
         else:
             optimizer.zero_grad(set_to_none=True)
             loss = compute_loss(model, x)
+            if reg_coeffs:
+                loss = loss + get_regularization(model, reg_coeffs)
             nfe_f = count_nfe(model)
             loss.backward()
             nfe_b = count_nfe(model) - nfe_f
