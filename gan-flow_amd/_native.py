@@ -81,9 +81,11 @@ def library_path(act="tanh"):
     if act not in ACTIVATIONS:
         raise CnfError("nonlinearity %r is not built into the HIP path (have: %s)" % (act, ", ".join(ACTIVATIONS)))
     # CNF_HIP_LIB: another build of the tanh library (kernel timing experiments, tools/build_variants.sh)
+    # CNF_HIP_LIBDIR: another build of all four libraries (tools/build_wide_ilp.sh)
+    here = os.environ.get("CNF_HIP_LIBDIR") or _HERE
     if act == "tanh":
-        return os.environ.get("CNF_HIP_LIB") or os.path.join(_HERE, "libcnf_hip.so")
-    return os.path.join(_HERE, "libcnf_hip_%s.so" % act)
+        return os.environ.get("CNF_HIP_LIB") or os.path.join(here, "libcnf_hip.so")
+    return os.path.join(here, "libcnf_hip_%s.so" % act)
 
 
 def load_library(act="tanh"):

@@ -108,6 +108,41 @@ __device__ __forceinline__ void load_weights_b16_global(SplitWeightsB16& wb, con
         }
 }
 
+// The same operands for a workgroup in which G waves (one producer, G - 1 helpers: cnf_split_fwd_tw.h) work on one feature
+// tile and need IDENTICAL operands: the conversion (two loads, eight three-piece splits and the packing per (layer, k-step)
+// unit) is divided among them -- wave `role` of the tile takes units role, role + G, ... -- and handed over through LDS
+// across the barrier that ends the kernel's staging; every wave then reads all twelve operands back (twelve 16-byte LDS
+// reads per lane).  Three waves converting everything each spent ~1 us of a launch on the SIMD's shared vector issue.
+// sh: [tile][unit = 2 l + ks][piece][lane].
+typedef u32x4 SplitWeightsShare[kNW][4][3][64];
+template <int D, int G>
+__device__ __forceinline__ void convert_weights_b16_shared(SplitWeightsShare& sh, const float* __restrict__ p, int tile, int role, int lane) {
+    const ParamLayout L = make_layout(D, kH);
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll 1
+    for (int u = role; u < 4; u += G) {   // role is uniform across the wave
+        const int l = u >> 1, ks = u & 1;
+        uint32_t pc[8][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* src = p + L.w(1 + l) + (16 * tile + j) * kH + 16 * (2 * ks + h) + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split3_bf16(src[r], pc[4 * h + r]);
+        }
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi) sh[tile][u][pi][lane] = __builtin_bit_cast(u32x4, mfma_b16_operand(pc, pi));
+    }
+}
+// ... behind the barrier
+__device__ __forceinline__ void collect_weights_b16_shared(SplitWeightsB16& wb, const SplitWeightsShare& sh, int tile, int lane) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi) wb.a[l][pi][ks] = __builtin_bit_cast(bf16x8, sh[tile][2 * l + ks][pi][lane]);
+}
+
 // Transposed weight pieces in LDS, one slice per wave: [layer][wave][k-step][piece][lane] = 8 bf16 of
 // W[16(2ks + h) + 4q + r][16 wave + j'] (the A operand of W^T . cotangent for the wave's own INPUT-feature tile, in the k
 // order of publish_b16).  48 KB.

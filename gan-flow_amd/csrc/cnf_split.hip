@@ -1805,15 +1805,21 @@ constexpr bool kFwdHelperWaves = false;
 constexpr bool kFwdHelperWaves = true;
 #endif
 
+// one helper group per tangent stream (twelve waves at d = 2 with the exact divergence: kFwdTwGroupsNote); 0 keeps one group
+#ifndef CNF_FWD_HELPER_GROUPS
+#define CNF_FWD_HELPER_GROUPS 1
+#endif
+
 template <int D, bool HUTCH>
 static hipError_t split_fwd_t(const SolveArgs& a, hipStream_t s) {
     const int grid = (int)((a.rows + kRows - 1) / kRows);
     if constexpr (D <= 2) {
         if (kFwdHelperWaves && !a.fwd4) {
-            hipError_t res = check_resident(dopri5_split_tw_kernel<D, HUTCH>, 2 * kThreads, grid);
+            constexpr int NH = (CNF_FWD_HELPER_GROUPS != 0 && !HUTCH) ? D : 1;
+            hipError_t res = check_resident(dopri5_split_tw_kernel<D, HUTCH, NH>, (1 + NH) * kThreads, grid);
             if (res != hipSuccess) return res;
             dbg_timing_begin(s);
-            hipLaunchKernelGGL((dopri5_split_tw_kernel<D, HUTCH>), dim3(grid), dim3(2 * kThreads), 0, s, a);
+            hipLaunchKernelGGL((dopri5_split_tw_kernel<D, HUTCH, NH>), dim3(grid), dim3((1 + NH) * kThreads), 0, s, a);
             dbg_timing_end(s);
             return hipGetLastError();
         }

@@ -13,6 +13,15 @@
 //   waves 4..7 ("helpers", H, the second wave of each SIMD): the tangent streams of the same feature tile, ONE INTERVAL
 //     BEHIND the producers -- tangent of layer l while the producers are at layer l + 1 -- then the divergence, and with it
 //     everything of log p: its slopes, its state, its share of the controller's sums, its dense output.
+//   Helper groups (kFwdTwGroupsNote): with the exact divergence at d = 2 there are two tangent streams, and a helper that
+//     carries both has twice the producers' matrix work per interval -- its chain, not the producers', bounded the
+//     eight-wave kernel.  That case runs TWELVE waves, three per SIMD (166 registers each, no spills): waves 4..7 carry
+//     tangent stream 0 and own log p, waves 8..11 carry tangent stream 1.  The second group keeps an identical copy of
+//     log p's state (it needs the controller's branches and barriers; it is never counted and stores nothing).
+//     Measured on the stiff trained field (B = 2 048): 2.74 -> 2.68 us per evaluation; what bounds an evaluation now is the
+//     producers' own chain and the three waves' shared vector issue between the last barrier of one evaluation and the first
+//     of the next (two further arrangements measured slower and not kept: the next stage's gates computed by a helper
+//     one evaluation ahead, 2.72; raised issue priority for the second helper group there, 2.74-2.76).
 // An evaluation keeps its three workgroup barriers; what a barrier interval holds is now one producer phase and one helper
 // phase side by side on each SIMD, and the dependent chain of an evaluation is the producers' alone.  The helpers' last
 // phase of evaluation e (third-layer tangents, last-layer dot products) runs beside the producers' first phase of e + 1;
@@ -106,19 +115,21 @@ struct FwdTwPending {
 };
 
 // the helpers' last phase of a pending evaluation: third-layer tangents, last-layer dot products -> partd
-template <int D, bool HUTCH>
-__device__ __forceinline__ void fwd_tw_helper_tail(const NetLdsSmall<D>& n, const SplitWeightsB16& wb, FwdTwLds<D, HUTCH>& xc, int lane, int tile) {
-    constexpr int NT = HUTCH ? 1 : D;
+// NSH streams from stream s0 on (kFwdTwGroupsNote: a helper group carries all NT tangent streams, or one of them)
+template <int D, bool HUTCH, int NSH>
+__device__ __forceinline__ void fwd_tw_helper_tail(const NetLdsSmall<D>& n, const SplitWeightsB16& wb, FwdTwLds<D, HUTCH>& xc, int lane, int tile, int s0) {
     const int q = lane >> 4, j = lane & 15, fo = 16 * tile + 4 * q;
-    f32x4 U[NT];
-    hidden_b16<NT>(xc.tp[1], wb, 1, lane, U);
+    f32x4 U[NSH];
+    hidden_b16<NSH>(xc.tp[1] + s0, wb, 1, lane, U);
     const f32x4 dg = xc.dg[2][tile][lane];
+    // exact divergence: tangent stream m feeds output m alone; Hutchinson: the one stream feeds every output
 #pragma unroll
-    for (int m = 0; m < D; ++m) {
+    for (int k = 0; k < (HUTCH ? D : NSH); ++k) {
+        const int m = HUTCH ? k : s0 + k;
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(&n.w4[m][fo]);
         float pd = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pd = fmaf(w4[r], dg[r] * U[HUTCH ? 0 : m][r], pd);
+        for (int r = 0; r < 4; ++r) pd = fmaf(w4[r], dg[r] * U[HUTCH ? 0 : k][r], pd);
         pd = xq_sum(pd);
         if (q == 0) xc.partd[tile][m][j] = pd;
     }
@@ -139,11 +150,10 @@ __device__ __forceinline__ float fwd_tw_helper_div(const FwdTwLds<D, HUTCH>& xc,
 // One evaluation, three barriers.  ROLE 1 = producer: returns f (field_fwd_split's value arithmetic).  ROLE 2 = helper:
 // first finishes the pending evaluation (tail before B1, divergence behind it: div_prev, valid when pend.on on entry),
 // then runs this evaluation's tangents up to the second hidden layer and leaves it pending.
-template <int D, bool HUTCH, int ROLE, class WS>
+template <int D, bool HUTCH, int ROLE, int NSH, class WS>
 __device__ __forceinline__ void fwd_eval_tw(const NetLdsSmall<D>& n, const SplitWeightsB16& wb, WS& ws, FwdTwLds<D, HUTCH>& xc, int lane,
-                                            int tile, float t, const float (&z)[D], const float (&e)[D], float (&f)[D],
+                                            int tile, int s0, float t, const float (&z)[D], const float (&e)[D], float (&f)[D],
                                             FwdTwPending<D>& pend, float& div_prev, Prof& pr) {
-    constexpr int NT = HUTCH ? 1 : D;
     constexpr bool P = ROLE == 1;
     pr.mark(0);   // [0]: between evaluations (Runge-Kutta bookkeeping, controller, reductions)
     const int q = lane >> 4, j = lane & 15;
@@ -167,7 +177,7 @@ __device__ __forceinline__ void fwd_eval_tw(const NetLdsSmall<D>& n, const Split
         xc.dg[0][tile][lane] = dg;
         publish_b16<1>(xc.xv[0], act, tile, lane);
     } else {
-        if (pend.on) fwd_tw_helper_tail<D, HUTCH>(n, wb, xc, lane, tile);
+        if (pend.on) fwd_tw_helper_tail<D, HUTCH, NSH>(n, wb, xc, lane, tile, s0);
     }
     pr.mark(1);        // [1]: S0 work
     __syncthreads();   // B1
@@ -193,7 +203,7 @@ __device__ __forceinline__ void fwd_eval_tw(const NetLdsSmall<D>& n, const Split
 #pragma unroll
         for (int m = 0; m < D; ++m) pend.g4[m] = sigmoid_f(fmaf(n.vec4[2][m], t, n.vec4[3][m]));
         const f32x4 dg = xc.dg[0][tile][lane];
-        f32x4 tg[NT];
+        f32x4 tg[NSH];
         if (HUTCH) {
             f32x4 au = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -202,13 +212,13 @@ __device__ __forceinline__ void fwd_eval_tw(const NetLdsSmall<D>& n, const Split
             for (int r = 0; r < 4; ++r) tg[0][r] = dg[r] * au[r];
         } else {
 #pragma unroll
-            for (int m = 0; m < NT; ++m) {
-                const f32x4 wcol = *reinterpret_cast<const f32x4*>(&n.w1[m][fo]);
+            for (int k = 0; k < NSH; ++k) {
+                const f32x4 wcol = *reinterpret_cast<const f32x4*>(&n.w1[s0 + k][fo]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tg[m][r] = dg[r] * wcol[r];
+                for (int r = 0; r < 4; ++r) tg[k][r] = dg[r] * wcol[r];
             }
         }
-        publish_b16<NT>(xc.tp[0], tg, tile, lane);
+        publish_b16<NSH>(xc.tp[0] + s0, tg, tile, lane);
     }
     pr.mark(3);        // [3]: S1 work
     __syncthreads();   // B2
@@ -237,15 +247,15 @@ __device__ __forceinline__ void fwd_eval_tw(const NetLdsSmall<D>& n, const Split
             if (q == 0) xc.partf[tile][m][j] = pf;
         }
     } else {
-        f32x4 U[NT];
-        hidden_b16<NT>(xc.tp[0], wb, 0, lane, U);
+        f32x4 U[NSH];
+        hidden_b16<NSH>(xc.tp[0] + s0, wb, 0, lane, U);
         const f32x4 dg = xc.dg[1][tile][lane];
-        f32x4 tg[NT];
+        f32x4 tg[NSH];
 #pragma unroll
-        for (int s = 0; s < NT; ++s)
+        for (int s = 0; s < NSH; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) tg[s][r] = dg[r] * U[s][r];
-        publish_b16<NT>(xc.tp[1], tg, tile, lane);
+        publish_b16<NSH>(xc.tp[1] + s0, tg, tile, lane);
         pend.on = true;
     }
     pr.mark(5);        // [5]: S2 work
@@ -261,10 +271,10 @@ __device__ __forceinline__ void fwd_eval_tw(const NetLdsSmall<D>& n, const Split
 }
 
 // before the controller looks at log p: the helpers finish the pending evaluation (one more barrier for everyone)
-template <int D, bool HUTCH, int ROLE>
-__device__ __forceinline__ void fwd_tw_drain(const NetLdsSmall<D>& n, const SplitWeightsB16& wb, FwdTwLds<D, HUTCH>& xc, int lane, int tile,
+template <int D, bool HUTCH, int ROLE, int NSH>
+__device__ __forceinline__ void fwd_tw_drain(const NetLdsSmall<D>& n, const SplitWeightsB16& wb, FwdTwLds<D, HUTCH>& xc, int lane, int tile, int s0,
                                              const float (&e)[D], FwdTwPending<D>& pend, float& div_prev) {
-    if constexpr (ROLE == 2) fwd_tw_helper_tail<D, HUTCH>(n, wb, xc, lane, tile);
+    if constexpr (ROLE == 2) fwd_tw_helper_tail<D, HUTCH, NSH>(n, wb, xc, lane, tile, s0);
     __syncthreads();
     if constexpr (ROLE == 2) {
         div_prev = fwd_tw_helper_div<D, HUTCH>(xc, pend, e, lane & 15);
@@ -273,13 +283,22 @@ __device__ __forceinline__ void fwd_tw_drain(const NetLdsSmall<D>& n, const Spli
 }
 
 // ---- the solve: controller of dopri5_split_kernel, state split over the roles (z: producers, log p: helpers) ----------------
-template <int D, bool HUTCH>
-__global__ __launch_bounds__(2 * kThreads) void dopri5_split_tw_kernel(SolveArgs a) {
+// NH helper groups (kFwdTwGroupsNote).  1: waves 4..7 carry all tangent streams.  d (exact divergence, d = 2): TWELVE waves,
+// three per SIMD -- waves 4..7 carry tangent stream 0 and own log p, waves 8..11 carry tangent stream 1 (and keep a second,
+// identical copy of log p's state so that they take the controller's branches; they are never counted).  A helper group's
+// barrier interval then holds one stream's matrix pass, like a producer's: the helpers' chain (two streams against the
+// producers' one) was the critical path of the eight-wave arrangement.  Same arithmetic per stream, same sums.
+template <int D, bool HUTCH, int NH>
+__global__ __launch_bounds__((1 + NH) * kThreads) void dopri5_split_tw_kernel(SolveArgs a) {
+    constexpr int NTHREADS = (1 + NH) * kThreads;
+    constexpr int NSH = (HUTCH ? 1 : D) / NH;   // tangent streams per helper group
+    static_assert(NH == 1 || (!HUTCH && NH == D), "one helper group, or one per tangent stream");
     const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
     __shared__ NetLdsSmall<D> net;              // no fp32 image of the two matrices: their pieces go from L2 straight to registers
     __shared__ SplitWaveLds<1> wl[kNW];         // gates per producer (their slopes live in xc.kz; kst is not used here)
     __shared__ FwdTwLds<D, HUTCH> xc;
     __shared__ RedLds red;
+    __shared__ SplitWeightsShare wshare;        // the tile's weight operands, converted once per workgroup (cnf_split.h)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // a scalar: the roles branch on it
     const int tile = wv & (kNW - 1);
@@ -295,14 +314,22 @@ __global__ __launch_bounds__(2 * kThreads) void dopri5_split_tw_kernel(SolveArgs
     }
     const float lp_in = a.logp0 ? a.logp0[rr] : 0.f;
     const int after_status = a.after ? a.after->status : 0;
-    // this wave's weight operands (both layers, three pieces) from the parameter vector: 8 x 16-byte loads per lane, in flight
-    // together with the rows' inputs and the staging of the small vectors (the four-wave kernel stages a 32 KB fp32 image
-    // in LDS first and splits from there: one more round trip and a barrier on a launch's fixed cost)
+    // this wave's weight operands (both layers, three pieces) from the parameter vector, in flight together with the rows'
+    // inputs and the staging of the small vectors (the four-wave kernel stages a 32 KB fp32 image in LDS first and splits from
+    // there: one more round trip and a barrier on a launch's fixed cost).  The waves of a tile divide the conversion.
     SplitWeightsB16 wb;
+#ifdef CNF_FWD_TW_OWN_WEIGHTS   // A/B timing: every wave converts all of its operands itself
     load_weights_b16_global<D>(wb, a.params, tile, lane);
-    stage_net_vectors<D>(net, a.params, tid, 2 * kThreads);
-    for (int idx = tid; idx < 7 * D * kRows; idx += 2 * kThreads) (&xc.kz[0][0][0])[idx] = 0.f;   // zero_slopes: 0 x stale NaN
+#else
+    convert_weights_b16_shared<D, 1 + NH>(wshare, a.params, tile, wv / kNW, lane);
+#endif
+    const int s0 = NH > 1 && wv >= kNW ? (wv / kNW - 1) * NSH : 0;   // helpers: first tangent stream of this wave's group
+    stage_net_vectors<D>(net, a.params, tid, NTHREADS);
+    for (int idx = tid; idx < 7 * D * kRows; idx += NTHREADS) (&xc.kz[0][0][0])[idx] = 0.f;   // zero_slopes: 0 x stale NaN
     __syncthreads();
+#ifndef CNF_FWD_TW_OWN_WEIGHTS
+    collect_weights_b16_shared(wb, wshare, tile, lane);
+#endif
 
     GridSync gs{a.gran, (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * D;
@@ -365,7 +392,7 @@ __global__ __launch_bounds__(2 * kThreads) void dopri5_split_tw_kernel(SolveArgs
 #pragma unroll
             for (int m = 0; m < D; ++m) zz[m] = yi[m];
         }
-        fwd_eval_tw<D, HUTCH, ROLE>(net, wb, ws, xc, lane, tile, sgn * ti, zz, ee, f, pend, div_prev, pr);
+        fwd_eval_tw<D, HUTCH, ROLE, NSH>(net, wb, ws, xc, lane, tile, s0, sgn * ti, zz, ee, f, pend, div_prev, pr);
         ++nfe;
         // helpers: the divergence that has just arrived belongs to the PREVIOUS evaluation (stage_prev of this attempt)
         if constexpr (H) {
@@ -373,7 +400,7 @@ __global__ __launch_bounds__(2 * kThreads) void dopri5_split_tw_kernel(SolveArgs
         }
         const bool ends = phase != PH_STAGE || stage == 6;    // the controller needs this evaluation's divergence: drain
         if (ends) {
-            fwd_tw_drain<D, HUTCH, ROLE>(net, wb, xc, lane, tile, ee, pend, div_prev);
+            fwd_tw_drain<D, HUTCH, ROLE, NSH>(net, wb, xc, lane, tile, s0, ee, pend, div_prev);
             if constexpr (H) k[0] = -sgn * (div_prev - res * (float)D);
         }
         if constexpr (P) {
@@ -520,18 +547,18 @@ __global__ __launch_bounds__(2 * kThreads) void dopri5_split_tw_kernel(SolveArgs
             }
         }
     }
-    // grid_cleanup for 2 * kThreads threads
+    // grid_cleanup for NTHREADS threads
     if (gs.nwg > 1) {
         if (tid == 0) red.last = taken == (unsigned)gs.nwg - 1u;
         __syncthreads();
         if (red.last) {
-            for (int i = tid; i < 2 * gs.nwg * 4; i += 2 * kThreads) gs.gran[i] = 0ull;
+            for (int i = tid; i < 2 * gs.nwg * 4; i += NTHREADS) gs.gran[i] = 0ull;
             if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(gs.gran + kGranWords), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     write_stats_global(a.stats, status, nfe, nacc, nrej, nfe, (float)dt, a.rows, tid);
 #ifdef CNF_PROF_CYCLES
-    if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == kNW) && nfe > 100)
+    if (blockIdx.x == 0 && lane == 0 && (wv % kNW) == 0 && nfe > 100)
         printf("fwd tw prof wave %d nfe %d cycles/eval: between %.0f | S0 %.0f wait B1 %.0f | S1 %.0f wait B2 %.0f | S2 %.0f wait B3 %.0f\n", wv, nfe,
                (double)pr.acc[0] / nfe, (double)pr.acc[1] / nfe, (double)pr.acc[2] / nfe, (double)pr.acc[3] / nfe, (double)pr.acc[4] / nfe,
                (double)pr.acc[5] / nfe, (double)pr.acc[6] / nfe);

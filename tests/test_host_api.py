@@ -424,12 +424,14 @@ def test_eight_wave_kernels_are_free_of_the_packed_fp32_hazard(act, tmp_path):
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not found")
     hazardous = re.compile(r"v_pk_(?:fma|mul|add)_f32\b.*op_sel:\[[01],1")
-    seen_eight_wave = 0
+    seen_eight_wave = seen_fwd_tw = 0
     for i, blob in enumerate(_gfx950_code_objects(_native.library_path(act))):
         f = tmp_path / ("co%d.hsaco" % i)
         f.write_bytes(blob)
         dis = subprocess.run([objdump, "-d", str(f)], capture_output=True, text=True, check=True).stdout
-        if "dopri5_bwd_split_kernel" not in dis:
+        # the translation units with kernels of more than one wave per SIMD: cnf_split.hip (eight-wave adjoint) and
+        # cnf_split_fwd.hip (eight- and twelve-wave forward solve, cnf_split_fwd_tw.h)
+        if "dopri5_bwd_split_kernel" not in dis and "dopri5_split_tw_kernel" not in dis:
             continue
         cur = None
         for line in dis.splitlines():
@@ -437,6 +439,8 @@ def test_eight_wave_kernels_are_free_of_the_packed_fp32_hazard(act, tmp_path):
             if m:
                 cur = m.group(1)
                 seen_eight_wave += "dopri5_bwd_split_kernel" in cur and cur.endswith("Lb1ELb1EEEvNS_9SolveArgsE")
+                seen_fwd_tw += "dopri5_split_tw_kernel" in cur
                 continue
             assert not hazardous.search(line), (cur, line.strip())
     assert seen_eight_wave >= 3     # d = 1, d = 2 exact, d = 2 Hutchinson
+    assert seen_fwd_tw >= 3
