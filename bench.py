@@ -406,7 +406,7 @@ def adjoint_roofline(model, x, spread, reps=20):
 def forward_roofline(model, x, reps=20):
     """The forward solve kernel of the timed step, as adjoint_roofline: rows x NFE x F_eval / mean kernel duration (HIP events
     recorded by the library around the kernel).  It is the kernel furthest below its roof: 128 workgroups on 256 compute units,
-    one wave per SIMD, a dependent chain per evaluation."""
+    a dependent chain per evaluation (three waves per SIMD: value stream, two tangent streams; cnf_split_fwd_tw.h)."""
     from gan_flow_amd import _native
     blk = model.chain[0]
     fn = blk.odefunc.odefunc
@@ -425,7 +425,7 @@ def forward_roofline(model, x, reps=20):
     st = _native.Stats(st)
     flops = rows * st.nfe * F_EVAL_D2
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "dopri5_split_tw_kernel<2,false>", "achieved": round(achieved, 4), "peak": PEAK_FP32_MATRIX_TFLOPS,
+    return {"bound": "mfma", "kernel": "dopri5_split_tw_kernel<2,false,2>", "achieved": round(achieved, 4), "peak": PEAK_FP32_MATRIX_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 5), "launch_ms": round(ms, 4), "nfe": st.nfe,
             "us_per_evaluation": round(1e3 * ms / st.nfe, 3), "flop_per_launch": flops,
             "peak_note": "dense fp32 matrix peak; FLOP counted as fp32 work (hidden layers on the bf16 pipe, three-piece operands)"}
