@@ -68,6 +68,7 @@ STATUS_MESSAGES = {
     2: "non-finite values in state `y`",
     3: "max_num_steps exceeded",
     4: "grid-wide reduction timed out inside the solver kernel",
+    5: "debug build (CNF_DEBUG_BOUNDS): a kernel formed a workspace range outside what cnf_workspace_bytes() names for the call",
 }
 EXPORTS = ("cnf_param_count", "cnf_workspace_bytes", "cnf_last_error", "cnf_eval_field", "cnf_solve_fwd",
            "cnf_eval_aug", "cnf_solve_bwd", "cnf_solve_bwd_train", "cnf_nll_loss", "cnf_adam_step", "cnf_debug_fill_lds",

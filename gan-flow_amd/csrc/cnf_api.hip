@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 
@@ -212,6 +213,17 @@ int cnf_debug_eval_field_b16(const CnfNetDesc* net, const float* params, float t
     return 0;
 }
 
+// debug build: CNF_DEBUG_SHRINK_WS=<bytes> makes the checker believe the workspace ends that many bytes early (the memory is
+// still there): the self-test of dbg_ws (tools/dbg_bounds_selftest.py) provokes a report without a real overrun
+static size_t dbg_shrink() {
+#ifdef CNF_DEBUG_BOUNDS
+    static const size_t v = [] { const char* e = getenv("CNF_DEBUG_SHRINK_WS"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }();
+    return v;
+#else
+    return 0;
+#endif
+}
+
 // what a FORWARD solve touches of its workspace: the granules, and at hidden width 256 the bf16 weight pieces behind them
 static size_t fwd_workspace_need(const CnfNetDesc* net) { return kGranBytes + (is_wide(net) ? kWidePieceBytes : 0); }
 
@@ -236,6 +248,8 @@ static int fill_common(const char* who, const CnfNetDesc* net, const float* para
     a.max_steps = opts->max_steps > 0 ? opts->max_steps : (1 << 20);
     a.gran = (unsigned long long*)workspace;
     a.slab = (float*)((char*)workspace + kGranBytes);
+    a.ws_lo = (const char*)workspace;
+    a.ws_hi = (const char*)workspace + need - dbg_shrink();
     a.stats = stats;
     a.n_grid = 1;
     a.residual = is_residual(net) ? 1 : 0;
@@ -441,6 +455,8 @@ int cnf_eval_aug(const CnfNetDesc* net, const float* params, float t, const floa
     a.e = e;
     a.gran = (unsigned long long*)workspace;
     a.slab = (float*)((char*)workspace + kGranBytes);
+    a.ws_lo = (const char*)workspace;
+    a.ws_hi = (const char*)workspace + need - dbg_shrink();
     a.grad_params = vjp_params_out;
     hipStream_t s = (hipStream_t)stream;
     if (is_wide(net)) {

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void aug_kernel(SolveArgs a, float t, con
         }
         nd_out[row] = -div;
     }
-    commit_step<D>(wl, acc, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, tid);
+    commit_step<D>(wl, acc, dbg_ws(a, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, sizeof(float) * make_layout(D, kH).total, __LINE__), tid);
 }
 
 // ---- the adjoint solve -------------------------------------------------------------------------------------
@@ -578,9 +578,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_kernel(SolveArgs a) {
     const bool counted = valid && lane < 16;
     const long rr = valid ? row : a.rows - 1;
     BwdWaveLds<D>& ws = wl[w];
-    float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;   // this workgroup's partial of a_theta
+    float* slab = dbg_ws(a, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, sizeof(float) * make_layout(D, kH).total, __LINE__);   // this workgroup's partial of a_theta
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * D;
 
     float y0[C], y1[C], yi[C], ee[D];
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(kThreads) void fixed_bwd_kernel(SolveArgs a) {
     const bool counted = valid && lane < 16;
     const long rr = valid ? row : a.rows - 1;
     BwdWaveLds<D>& ws = wl[w];
-    float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;   // this workgroup's partial of a_theta
+    float* slab = dbg_ws(a, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, sizeof(float) * make_layout(D, kH).total, __LINE__);   // this workgroup's partial of a_theta
 
     float y[C], ee[D];
 #pragma unroll

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NW * 64)
     const long rr = row < a.rows ? row : a.rows - 1;
     WaveLds<D>& ws = wl[w];
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     double nz, nl;  // element counts of the z and logp tensors of the control group
     if (GLOBAL) {
         nl = (double)a.rows;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(NW * 64)
 #pragma unroll
                 for (int s = 0; s < 7; ++s) ks_[s] = krs[w][s][q_][j];
                 const float v = dense_quartic(dtf, x, r0[q_], r1[q_], ks_);
-                if (counted && q_ < nreg) a.reg_rows[(long)q_ * a.rows + row] = v;
+                if (counted && q_ < nreg) dbg_ws(a, a.reg_rows, sizeof(float) * nreg * a.rows, __LINE__)[(long)q_ * a.rows + row] = v;
             }
         }
     }

@@ -51,7 +51,45 @@ struct SolveArgs {
     float* reg_rows;             // forward: every row's integral of its regularisers' integrands, [nreg][rows]
     const float* reg_val;        // adjoint: the regularisation states at t1 (device, nreg floats)
     const float* reg_cot;        // adjoint: dL/d(state) (device, nreg floats)
+    // the bytes of the caller's workspace this call may touch: [workspace, workspace + cnf_workspace_bytes(net, rows)) -- what a
+    // caller that allocates exactly the advertised size owns.  Read by the debug build only (dbg_ws below).
+    const char* ws_lo;
+    const char* ws_hi;
 };
+
+// ---- debug build: `make debug` (-DCNF_DEBUG_BOUNDS; libraries in gan-flow_amd/debug/, loaded through CNF_HIP_LIBDIR) ----------
+// Every sub-range of the workspace that a kernel derives from its block index, a slot index or the launch geometry -- gradient
+// slabs, stage slots and running totals, weight-piece areas, the granule banks -- passes through dbg_ws() where the pointer is
+// formed.  Release build: the identity, no code.  Debug build: a range outside [ws_lo, ws_hi) is reported (site = source line,
+// block, wave, offsets), the solve's status word is raised to CNF_ERR_DEBUG_BOUNDS, and the pointer is redirected to the
+// workspace's first bytes so that the run ends with a status instead of a GPU fault (a fault can take the whole node down).
+// Row-indexed inputs and outputs are clamped to [0, rows) where the index is formed, and the parameter vector is indexed by
+// compile-time layouts: neither needs a run-time check.
+template <class T>
+__device__ __forceinline__ T* dbg_ws(const SolveArgs& a, T* p, size_t bytes, int site) {
+#ifdef CNF_DEBUG_BOUNDS
+    const char* c = reinterpret_cast<const char*>(p);
+    if (a.ws_hi != nullptr && (c < a.ws_lo || c + bytes > a.ws_hi)) {
+        if ((threadIdx.x & 63) == 0)
+            printf("CNF_DEBUG_BOUNDS line %d block %d wave %d: range [%ld, %ld) of a workspace of %ld bytes\n", site, (int)blockIdx.x,
+                   (int)(threadIdx.x >> 6), (long)(c - a.ws_lo), (long)(c - a.ws_lo) + (long)bytes, (long)(a.ws_hi - a.ws_lo));
+        if (a.stats) atomicMax(&a.stats->status, (int)CNF_ERR_DEBUG_BOUNDS);
+        return reinterpret_cast<T*>(const_cast<char*>(a.ws_lo));
+    }
+#endif
+    return p;
+}
+// the granule banks and the ticket word behind them (GridSync, cnf_device.h): kGranWords + 1 eight-byte words, and a grid that
+// fits the banks
+__device__ __forceinline__ unsigned long long* dbg_gran(const SolveArgs& a, int site) {
+#ifdef CNF_DEBUG_BOUNDS
+    if (gridDim.x > (unsigned)kMaxWG) {
+        if (threadIdx.x == 0) printf("CNF_DEBUG_BOUNDS line %d: grid of %d workgroups, granule banks hold %d\n", site, (int)gridDim.x, kMaxWG);
+        if (a.stats) atomicMax(&a.stats->status, (int)CNF_ERR_DEBUG_BOUNDS);
+    }
+#endif
+    return dbg_ws(a, a.gran, (size_t)(kGranWords + 1) * sizeof(unsigned long long), site);
+}
 
 hipError_t launch_field(int D, bool hutch, const float* params, float t, const float* z, const float* e, long rows,
                         float* f_out, float* nd_out, hipStream_t s, float res = 0.f, bool b16 = false);

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split_kernel(SolveArgs a) {
     wb.load(net, w, lane);
     SplitWaveLds<C>& ws = wl[w];
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * D;
 
 #pragma unroll
@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(kThreads) void aug_split_kernel(SolveArgs a, float 
         }
         nd_out[row] = -div;
     }
-    commit_step_split<D>(sb, acc, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, tid);
+    commit_step_split<D>(sb, acc, dbg_ws(a, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, sizeof(float) * make_layout(D, kH).total, __LINE__), tid);
 }
 
 // RUNTOT: the launch has two workgroups per tile (a.spread) and each keeps ONE matrix: accumulators of 16 registers, so
@@ -1270,9 +1270,9 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     const bool counted = valid && lane < 16 && wv == 0 && part != 2;
     const long rr = valid ? row : a.rows - 1;
     SplitWaveLds<C>& ws = wl[SHARE ? 0 : w];
-    float* slab = a.slab + (size_t)blockIdx.x * make_layout(D, kH).total;
+    float* slab = dbg_ws(a, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, sizeof(float) * make_layout(D, kH).total, __LINE__);
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * D;
 
     // a.loss_out: the cotangents are those of loss = -mean(sum_d log N(z1_d) - logp1) (nll_loss_kernel's arithmetic,

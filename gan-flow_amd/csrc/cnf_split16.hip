@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void dopri5_split16_kernel(SolveArgs a) {
     const long rr = row < a.rows ? row : a.rows - 1;
     Wave16Lds& ws = wl[w];
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * kD;
 
     float y0[kC], y1[kC], yi[kC];
@@ -745,9 +745,9 @@ __global__ __launch_bounds__(kThreads) void dopri5_bwd_split16_kernel(SolveArgs 
     const bool cz = valid && w == 0 && part != 2;
     const bool cl = cz && q == 0;
     const long rr = valid ? row : a.rows - 1;
-    float* slab = a.slab + (size_t)blockIdx.x * L.total;
+    float* slab = dbg_ws(a, a.slab + (size_t)blockIdx.x * L.total, sizeof(float) * L.total, __LINE__);
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * kD;
 
     // a.loss_out: NLL cotangents and the loss on the second grid reduction (see dopri5_bwd_split_kernel, cnf_split.hip)
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(kThreads) void fixed_bwd_split16_kernel(SolveArgs a
     const bool cz = valid && w == 0;
     const bool cl = cz && q == 0;
     const long rr = valid ? row : a.rows - 1;
-    float* slab = a.slab + (size_t)blockIdx.x * L.total;
+    float* slab = dbg_ws(a, a.slab + (size_t)blockIdx.x * L.total, sizeof(float) * L.total, __LINE__);
 
     float y[kCA];
     const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.e + rr * kD + 4 * q);

@@ -331,7 +331,7 @@ __global__ __launch_bounds__((1 + NH) * kThreads) void dopri5_split_tw_kernel(So
     collect_weights_b16_shared(wb, wshare, tile, lane);
 #endif
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * D;
 
     auto run = [&](auto role_c) __attribute__((always_inline)) {

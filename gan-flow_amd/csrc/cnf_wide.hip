@@ -352,7 +352,7 @@ void wide_dopri5_kernel(SolveArgs a) {   // (bf16 path: no register cap -- its p
     const long rr = row < a.rows ? row : a.rows - 1;
     WideWaveLds<C>& ws = wl[w];
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     const double nl = GLOBAL ? (double)a.rows : (double)(a.rows - base < kRows ? a.rows - base : kRows);
     const double nz = nl * D;
 
@@ -391,7 +391,7 @@ void wide_dopri5_kernel(SolveArgs a) {   // (bf16 path: no register cap -- its p
         bool restart = false;
 #pragma unroll
         for (int m = 0; m < D; ++m) zz[m] = yi[m];
-        field_fwd_wide<D, HUTCH>(net, ws, xc, a.params, lane, w, sgn * ti, zz, ee, f, div, reinterpret_cast<const u32x4*>(a.slab));
+        field_fwd_wide<D, HUTCH>(net, ws, xc, a.params, lane, w, sgn * ti, zz, ee, f, div, reinterpret_cast<const u32x4*>(dbg_ws(a, a.slab, kWidePieceBytes, __LINE__)));
         #pragma unroll
         for (int m = 0; m < D; ++m) f[m] = fmaf(-res, zz[m], f[m]);   // residual dynamics f(z) - z (res = 0 or 1)
         div -= res * (float)D;

@@ -583,6 +583,7 @@ __global__ __launch_bounds__(kThreads) void wide_aug_kernel(SolveArgs a, const f
     constexpr int C = 2 * D + 1;
     __shared__ WideBwdShared<D, NS, C, kWideBwdB16> sh;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
+    wt = dbg_ws(a, wt, sizeof(float) * kWideBwdHeadFloats, __LINE__);
     sh.stage(a.params, tid);
     __syncthreads();
     const long row = (long)blockIdx.x * kRows + j;
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(kThreads) void wide_aug_kernel(SolveArgs a, const f
         az[m] = valid ? a_z[rr * D + m] : 0.f;
     }
     const float al = valid ? a_l[rr] : 0.f;
-    float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
+    float* region = dbg_ws(a, a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>, sizeof(float) * kWideSlots * kWideSlotF<D>, __LINE__);
     aug_eval_sh<D, HUTCH, false>(sh, a.params, wt, lane, w, t, zz, ee, az, al, 1.0f, true, f, div, vz, region);
     #pragma unroll
     for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
     __shared__ float wq[8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15;
     if (tid == 0) red.status = 0;
+    wt = dbg_ws(a, wt, sizeof(float) * kWideBwdHeadFloats, __LINE__);
     sh.stage(a.params, tid);
     sh.zero(tid);
     __syncthreads();
@@ -637,9 +639,9 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
     const bool counted = valid && lane < 16 && w == 0 && part != 2;
     const long rr = valid ? row : a.rows - 1;
     float (&kst)[7][C][kRows] = sh.kst(w);
-    float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
+    float* region = dbg_ws(a, a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>, sizeof(float) * kWideSlots * kWideSlotF<D>, __LINE__);
 
-    GridSync gs{a.gran, (int)gridDim.x, 0u};
+    GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
     const double nl = (double)a.rows, nz = nl * D;
 
     float y0[C], y1[C], yi[C], ee[D];
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(kThreads) void wide_bwd_kernel(SolveArgs a, const f
         if constexpr ((kWideRematLane & 1) != 0) asm volatile("" : "+v"(lane_e));
         if constexpr ((kWideRematLane & 4) != 0) asm volatile("" : "+v"(lane_r));
         aug_eval_sh<D, HUTCH, kWideBwdB16>(sh, a.params, wt, lane_e, w, sgn * ti, zz, ee, az, al, sgn, with_theta, f, div, vz,
-                              region + (size_t)slot_i * kWideSlotF<D>, part);
+                              dbg_ws(a, region + (size_t)slot_i * kWideSlotF<D>, sizeof(float) * kWideSlotF<D>, __LINE__), part);
         #pragma unroll
         for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
             f[m] = fmaf(-res, zz[m], f[m]);
@@ -905,7 +907,7 @@ __global__ __launch_bounds__(kThreads) void wide_fixed_bwd_kernel(SolveArgs a, c
     const bool valid = row < a.rows;
     const bool counted = valid && lane < 16 && w == 0;
     const long rr = valid ? row : a.rows - 1;
-    float* region = a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>;
+    float* region = dbg_ws(a, a.slab + (size_t)blockIdx.x * kWideSlots * kWideSlotF<D>, sizeof(float) * kWideSlots * kWideSlotF<D>, __LINE__);
 
     float y[C], ee[D];
 #pragma unroll

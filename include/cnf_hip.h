@@ -87,7 +87,8 @@ enum { CNF_FLAG_CLEAN = 1, CNF_FLAG_SPREAD = 2, CNF_FLAG_ADJ_CONTROL_ALL = 4, CN
 /* CNF_FLAG_FWD_FOUR_WAVES (cnf_solve_fwd, cnf_solve_fwd_static; diagnostics): run a batch-global dopri5 forward solve of
  * hidden width 64, dim <= 2, at most 4096 rows on the four-wave kernel (every wave carries the value and the tangent
  * streams of its feature tile) instead of the eight-wave one (value stream on four waves, tangent streams and log p on the
- * second wave of each SIMD, one barrier interval behind).  Same arithmetic, identical bits; for A/B timing and the test
+ * second wave of each SIMD, one barrier interval behind; twelve waves -- a helper group per tangent stream -- at dim 2 with
+ * the exact divergence).  Same arithmetic, identical bits; for A/B timing and the test
  * that holds the two kernels to each other.  Ignored where the eight-wave kernel does not apply.                        */
 
 /* CNF_FLAG_SPREAD (cnf_solve_bwd, at most half as many 16-row tiles as the device has
@@ -113,7 +114,10 @@ enum {
     CNF_ERR_DT_UNDERFLOW = 1, /* torchdiffeq: "underflow in dt"                                   */
     CNF_ERR_NONFINITE = 2,    /* torchdiffeq: "non-finite values in state `y`"                    */
     CNF_ERR_MAX_STEPS = 3,    /* torchdiffeq: max_num_steps exceeded                              */
-    CNF_ERR_SYNC_TIMEOUT = 4  /* a grid-wide reduction did not complete (should never happen)     */
+    CNF_ERR_SYNC_TIMEOUT = 4, /* a grid-wide reduction did not complete (should never happen)     */
+    CNF_ERR_DEBUG_BOUNDS = 5  /* debug build only (`make -C gan-flow_amd/csrc debug`, -DCNF_DEBUG_BOUNDS): a kernel derived a
+                                 sub-range of the workspace that lies outside the bytes cnf_workspace_bytes() names for the
+                                 call; the access was redirected to the workspace's first bytes and the details printed */
 };
 
 /* Written by the kernels (device memory, 32 bytes).  For tile-local step control the counters are the
