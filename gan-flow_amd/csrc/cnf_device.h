@@ -827,6 +827,22 @@ struct GridSync {
 };
 
 constexpr unsigned kSpinLimit = 1u << 24;
+// Before its first sweep the polling wave sleeps CNF_PRE_POLL_SLEEP x 64 clocks (~0.55 us).  An agent-scope store needs about that
+// long to become visible to the other compute units, so a sweep issued right behind the workgroup's own publish cannot succeed
+// when the workgroups arrive together (they do: they run the same evaluations) -- and 128..256 pollers reading the same 4..8 KB
+// of granules are a hot spot at the memory side, so the futile sweep also delays the stores it is waiting for.  Measured on
+// the forward solve (B = 2 048, 128 workgroups; tools/time_kernels.py, time_prologue.py): stiff field 2.65 -> 2.55 us per
+// evaluation and NFE-14 launch 52.1 -> 49.4 us at 20; 8 / 12 / 16 / 24 / 32: 2.62 / 2.62 / 2.59 / 2.56 / 2.61.  Two sweeps in
+// flight instead (more polling, earlier detection) measured SLOWER (2.70), a longer sleep between sweeps neutral.
+// Applied where it was measured: the eight- / twelve-wave forward solve (tw_allreduce4, cnf_split_fwd_tw.h).  wg_allreduce4
+// below keeps its immediate first sweep (CNF_PRE_POLL_SLEEP_WG, default 0): with it on, the H = 256 figures of the bench came
+// out 2-3 % lower (long evaluations, workgroups that do not arrive together) and the d = 16 ones unchanged.
+#ifndef CNF_PRE_POLL_SLEEP
+#define CNF_PRE_POLL_SLEEP 20
+#endif
+#ifndef CNF_PRE_POLL_SLEEP_WG
+#define CNF_PRE_POLL_SLEEP_WG 0
+#endif
 
 // returns false on timeout (status set in red.status).  All threads of the workgroup must call it.
 // ALLQ: all four lane quarters of a wave carry contributions (cnf_split16.hip), not just quarter 0.
@@ -867,9 +883,7 @@ __device__ inline bool wg_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
             const int ng = gs.nwg * 4;
             double acc = 0.0;
             bool done = false;
-#ifdef CNF_PRE_POLL_SLEEP   // experiment: let the store (and the others') travel before the first sweep is issued
-            __builtin_amdgcn_s_sleep(CNF_PRE_POLL_SLEEP);
-#endif
+            if (CNF_PRE_POLL_SLEEP_WG > 0) __builtin_amdgcn_s_sleep(CNF_PRE_POLL_SLEEP_WG);   // note above
             // every lane polls its granules (g = lane, lane + 64, ...) with ALL loads of a sweep in flight at once: a
             // sweep then costs one L2 round trip instead of one per granule
             constexpr int kPerLane = kMaxWG * 4 / 64;

@@ -76,6 +76,7 @@ __device__ inline bool tw_allreduce4(GridSync& gs, RedLds& red, double (&v)[4], 
             double acc = 0.0;
             bool done = false;
             constexpr int kPerLane = kMaxWG * 4 / 64;
+            __builtin_amdgcn_s_sleep(CNF_PRE_POLL_SLEEP);   // the first sweep cannot succeed earlier (cnf_device.h)
             for (unsigned spin = 0; spin < kSpinLimit; ++spin) {
                 unsigned long long x[kPerLane];
 #pragma unroll
