@@ -213,6 +213,12 @@ def test_solve_bwd_stiff_trained_field(dim, spread, train):
              s_b.n_accepted, s_b.n_rejected, bo["n_accepted"], bo["n_rejected"]))
     assert abs(n_f - n_fo) <= 0.03 * n_fo and abs(n_b - n_bo) <= 0.03 * n_bo
     assert s_b.nfe == 2 + 6 * n_b and s_b.evals_run == s_b.nfe       # FSAL: nothing re-evaluated
+    # Regression pin of the KERNELS' own step sequences on this fixture (recorded on MI355X, round 3).  The controller's
+    # arithmetic is restated, not shared, with the oracle (e.g. the fifth root of next_step_size is a seeded Newton iteration,
+    # cnf_device.h, where the oracle calls pow): a change there that moves one accept / reject decision among these ~330
+    # attempts shows up here even while the 3 % band above still holds.  Update deliberately, with the reason.
+    pinned = {1: ((254, 87), (240, 81)), 2: ((254, 76), (247, 78))}[dim]
+    assert ((s_f.n_accepted, s_f.n_rejected), (s_b.n_accepted, s_b.n_rejected)) == pinned
     assert torch.equal(gl0.cpu(), torch.full((rows, 1), 1.0 / rows))
     gx64, gp64 = gold["grad_x"], gold["grad_theta"]
     # grad_x: max-norm distance to the float64 solution, hip vs oracle
