@@ -48,7 +48,7 @@ def parse():
     p.add_argument("--mode", type=str, default="fused", choices=["fused", "graph", "eager"],
                    help="fused: gu_ffjord.FusedTrainStep (solves + cnf_nll_loss + cnf_adam_step, one hipGraph replay per "
                         "iteration); graph: autograd + torch.optim.Adam loop captured as one hipGraph; eager: that loop, launched eagerly")
-    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,wide,pair,cpu,config1,repeats",
+    p.add_argument("--extras", type=str, default="roofline,late,eval,d16,wide,rk4,pair,cpu,config1,repeats",
                    help="comma list of the additional measurements to run: roofline, late, eval, d16, wide, pair, cpu, config1, "
                         "repeats ('' = none)")
     p.add_argument("--repeats", type=int, default=5, help="extra repeats of the timed loop (fresh seed-1 model each) for the spread keys")
@@ -285,6 +285,8 @@ def main():
         out["d16_hutchinson"] = measure_d16(ctx)
     if "wide" in extras:
         out["h256_4blocks"] = measure_wide(ctx)
+    if "rk4" in extras:
+        out["rk4_training"] = measure_rk4(ctx)
     if "cpu" in extras and rank == 0 and world == 1 and args.cpu_iters > 0:
         out["cpu_baseline"] = measure_cpu(ctx)
 
@@ -494,6 +496,31 @@ def measure_d16(ctx):
             "workload": "FFJORD CNF on the synthetic d=16 8-component Gaussian mixture, B=%d, ODEnet 16-64-64-64-16, "
                         "Hutchinson divergence (Gaussian probe, fresh per iteration), dopri5 1e-5, adjoint, Adam; "
                         "seed 1+rank per GPU" % args.batch}
+
+
+def measure_rk4(ctx):
+    """The headline's training iteration with the fixed-grid solver north_star names for parity (`gu_maf --solver rk4
+    --step_size 0.05`: 10 steps of the 3/8 rule each way, NFE 40 / 40) on the one-tile-per-workgroup fixed-grid kernels."""
+    from gan_flow_amd import gu_ffjord
+    args, dev = ctx["args"], ctx["dev"]
+    torch.manual_seed(1 + ctx["rank"])
+    model = gu_ffjord.build_model(2, solver="rk4").to(dev).train()
+    for blk in model.chain:
+        blk.solver_options = {"step_size": 0.05}
+    xs = ctx["batches"]
+    step = gu_ffjord.FusedTrainStep(model, xs[0], lr=1e-3, weight_decay=1e-5, graph=True, spread=ctx["spread"],
+                                    warmup_batches=xs[:max(1, args.warmup)])
+    ctx["barrier"]()
+    t0 = time.perf_counter()
+    for x in xs[args.warmup:args.warmup + args.steps]:
+        step(x)
+    ctx["barrier"]()
+    el = ctx["max_over_ranks"](time.perf_counter() - t0)
+    nfe_f, nfe_b = step.check()
+    return {"value": round(ctx["world"] * args.steps / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+            "nfe_forward": nfe_f, "nfe_backward": nfe_b,
+            "workload": "the headline's model and batches trained with --solver rk4 --step_size 0.05 (3/8 rule, fixed grid, "
+                        "adjoint on the same grid), B=%d" % args.batch}
 
 
 def measure_pair(ctx):

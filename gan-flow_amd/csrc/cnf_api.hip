@@ -21,6 +21,8 @@ hipError_t launch_wide_fixed_bwd(int D, bool hutch, const SolveArgs& a, float* w
 // feature-split (one tile per workgroup) variants, cnf_split.hip
 hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
+hipError_t launch_split_fixed_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
+hipError_t launch_split_fixed_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s);
 hipError_t launch_split_aug(int D, bool hutch, const SolveArgs& a, float t, const float* z, const float* a_z,
                             const float* a_l, float* f_out, float* nd_out, float* vz_out, hipStream_t s);
 // loss and optimizer step, cnf_train.hip
@@ -329,6 +331,8 @@ int solve_fwd_impl(const char* who, bool library_scratch, const CnfNetDesc* net,
     if (err == hipSuccess) {
         if (is_wide(net)) err = cnf::launch_wide_solve(net->dim, hutch, a, opts->solver, global, s);
         else if (opts->solver == CNF_SOLVER_DOPRI5 && global && use_split(net, rows)) err = cnf::launch_split_fwd(net->dim, hutch, a, s);
+        // fixed-grid solves of up to 4096 rows: one tile per workgroup (cnf_split_fwd_tw.h, kFixedSplitNote)
+        else if (opts->solver != CNF_SOLVER_DOPRI5 && net->dim <= 2 && use_split(net, rows) && !a.fwd4) err = cnf::launch_split_fixed_fwd(net->dim, hutch, a, s);
         else err = cnf::launch_solve_fwd(net->dim, hutch, a, opts->solver, global, s);
     }
     if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
@@ -501,7 +505,10 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
                     "cnf_solve_bwd and cnf_adam_step", who, cnf::kRows * cnf::kMaxWG, net->hidden, (long)rows);
     const bool fixed = opts->solver != CNF_SOLVER_DOPRI5;   // euler / midpoint / rk4: the adjoint runs on the same fixed grid, backwards
     if (fixed) {
-        if (train) return fail("%s: built for dopri5; fixed-grid training goes through cnf_solve_bwd and cnf_adam_step", who);
+        // cnf_solve_bwd_train on a fixed grid: the one-tile-per-workgroup kernels (cnf_split.hip) with the caller's cotangents
+        if (train && (nll || net->dim > 2 || (opts->flags & CNF_FLAG_FWD_FOUR_WAVES)))
+            return fail("%s: with a fixed-grid solver it takes explicit cotangents (cnf_nll_loss), dim <= 2 and no "
+                        "CNF_FLAG_FWD_FOUR_WAVES; otherwise cnf_solve_bwd and cnf_adam_step", who);
         if (!is_wide(net) && net->dim <= 2 && rows > kFixedBwdMaxRows)
             return fail("%s: the fixed-grid adjoint supports at most %ld rows per call (got %ld)", who, (long)kFixedBwdMaxRows, (long)rows);
         if (opts->step_size > 0.f) {
@@ -551,6 +558,12 @@ int solve_bwd_impl(const char* who, bool train, const CnfNetDesc* net, const flo
         if ((al & 15) != 0) return fail("%s: the fixed-grid adjoint at dim 16 needs 16-byte aligned z1, e, grad_z1, grad_x and params", who);
         err = zero_async(stats, 0, sizeof(CnfStats), s);
         if (err == hipSuccess) err = cnf::launch_split16_fixed_bwd(a, s);
+        if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
+        return 0;
+    }
+    if (fixed && use_split(net, rows) && !a.fwd4) {   // one tile per workgroup (cnf_split.hip, fixed_bwd_split_kernel): the slabs are stored
+        err = zero_async(stats, 0, sizeof(CnfStats), s);
+        if (err == hipSuccess) err = cnf::launch_split_fixed_bwd(net->dim, hutch, a, s);
         if (err != hipSuccess) return fail("%s: launch failed: %s", who, hipGetErrorString(err));
         return 0;
     }

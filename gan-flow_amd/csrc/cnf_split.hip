@@ -1692,6 +1692,178 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     }
 }
 
+// ---- the adjoint solve on a fixed grid, one tile per workgroup (kFixedSplitNote, cnf_split_fwd_tw.h) -------------------------
+// fixed_bwd_kernel (cnf_bwd.hip: one wave per tile, 32 workgroups at the training batch size) with the feature-split
+// augmented evaluation of the dopri5 adjoint above: same grid on the negated time axis (points tau_i = -t1 + i h, the last
+// clipped to -t0), same stage states and update expressions, same quadrature weights of the stages' vjp_theta (rk4 = the
+// 3/8 rule's dt/8 (1, 3, 3, 1); midpoint: the second stage only; euler: dt).  No step control: nothing is rejected, so the
+// weighted sums of ALL steps gather in one accumulator set and the slab is stored once, when the solve ends.
+// TW = false: four waves, both matrices' sums in registers (BigAccS), the small parameters' in sb.small[0].
+// TW = true (a.spread: two workgroups per tile, each keeping half of the sums): eight waves, producers and theta waves
+// (kThetaWavesNote); a theta wave stores what it owns (store_total_regs).
+template <int D, bool HUTCH, bool TW>
+__global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void fixed_bwd_split_kernel(SolveArgs a) {
+    static_assert(kFsalTheta<D> && kBwdB16<D>, "d <= 2 (d = 16: cnf_split16.hip)");
+    constexpr int NTH = TW ? 2 * kThreads : kThreads;
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
+    constexpr int C = 2 * D + 1;
+    constexpr bool SHARE = kShareWaveLds<D> || TW;
+    __shared__ BwdNet<D> net;
+    __shared__ SplitBwdLds<D, TW> sb;
+    __shared__ SplitWaveLds<C> wl[SHARE ? 1 : kNW];
+    __shared__ BwdXchg<D> xc;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15;
+    const int wv = TW ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+    const int w = TW ? (wv & (kNW - 1)) : wv;
+    const int tile = TW ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;   // kSpreadNote
+    const int part = TW ? 1 + (int)(blockIdx.x & 1) : 0;
+    const long row = (long)tile * kRows + j;
+    const bool valid = row < a.rows;
+    const bool counted = valid && lane < 16 && wv == 0 && part != 2;
+    const long rr = valid ? row : a.rows - 1;
+    SplitWaveLds<C>& ws = wl[SHARE ? 0 : w];
+    float* slab = dbg_ws(a, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, sizeof(float) * make_layout(D, kH).total, __LINE__);
+
+    float y[C], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        y[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+        y[D + 1 + m] = valid ? a.grad_z1[rr * D + m] : 0.f;   // padded rows carry zero adjoints: they add nothing to any sum
+    }
+    y[D] = a.logp0[rr];
+    const float al = valid ? a.grad_logp1[rr] : 0.f;   // d(a_logp)/dt = 0: constant along the solve
+    const int status = a.after ? a.after->status : 0;  // CnfSolverOpts.after: the solve whose output this one consumes failed
+    SplitWeightsB16 wb;
+    stage_bwd_net<D, NTH>(net, sb, wb, a.params, tid);
+    if constexpr (!TW)
+        for (int i = tid; i < (int)(sizeof(sb.small) / sizeof(float)); i += NTH) (&sb.small[0][0])[i] = 0.f;
+    __syncthreads();
+
+    const int nst = a.fixed_kind == CNF_SOLVER_EULER ? 1 : (a.fixed_kind == CNF_SOLVER_MIDPOINT ? 2 : 4);
+    const int n_steps = status == 0 ? a.n_grid : 0;
+
+    // once per role (kThetaWavesNote): 0 = a wave of a four-wave workgroup, 1 = producer, 2 = theta wave
+    auto run = [&](auto role_c) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr bool P = ROLE != 2, T = ROLE != 1;
+    using AccT = typename std::conditional<TW, ThetaAccT<D>, BigAccS>::type;
+    AccT acc, unused;
+    acc.zero();
+    unused.zero();
+    // the adjoint pass runs from t1 back to t0
+    const float sgn = a.t0 >= a.t1 ? 1.f : -1.f;
+    const float tau0 = sgn * a.t1, tau1 = sgn * a.t0;
+    Prof pr;
+    for (int step = 0; step < n_steps; ++step) {
+        // grid point i = i*step_size + tau0 (product rounded before the add, like arange()*h + t0): fixed_bwd_kernel's arithmetic
+        const float ta = a.n_grid == 1 ? tau0 : __fadd_rn(__fmul_rn((float)step, a.step_size), tau0);
+        const float tb = (step + 1 == a.n_grid) ? tau1 : __fadd_rn(__fmul_rn((float)(step + 1), a.step_size), tau0);
+        const float dt = tb - ta;
+        float k1[C], k2[C], k3[C], yi[C];
+        float ti = ta;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            yi[c] = y[c];
+            k1[c] = k2[c] = k3[c] = 0.f;
+        }
+        for (int st = 0; st < nst; ++st) {
+            float zz[D], az[D], f[D], vz[D], div = 0.f, k[C];
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                zz[m] = yi[m];
+                az[m] = yi[D + 1 + m];
+                f[m] = vz[m] = 0.f;
+            }
+            // weight of this stage's vjp_theta in the step's increment of a_theta
+            float wq;
+            if (a.fixed_kind == CNF_SOLVER_EULER) wq = dt;
+            else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) wq = st == 0 ? 0.f : dt;
+            else wq = (st == 0 || st == 3) ? dt / 8 : 3 * (dt / 8);
+            int lane_e = lane;   // kRematLaneNote
+            if constexpr (TW && (kRematLane & ROLE) != 0) asm volatile("" : "+v"(lane_e));
+            aug_eval_split<D, HUTCH, ROLE>(net, wb, sb, ws, xc, lane_e, w, sgn * ti, zz, ee, az, al, sgn * wq, wq != 0.f, f, div, vz, acc,
+                                           unused, false, 0, part, pr, NoMid{});
+            if constexpr (P) {
+#pragma unroll
+                for (int m = 0; m < D; ++m) {   // residual dynamics f(z) - z (res = 0 or 1): d/dz gains -I
+                    f[m] = fmaf(-res, zz[m], f[m]);
+                    vz[m] = fmaf(res, az[m], vz[m]);
+                }
+                div -= res * (float)D;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    k[m] = sgn * f[m];
+                    k[D + 1 + m] = sgn * vz[m];
+                }
+                k[D] = -sgn * div;
+            }
+            // fixed_bwd_kernel's updates; a theta wave only follows the evaluation times (its gate factors need them)
+            if (a.fixed_kind == CNF_SOLVER_EULER) {            // y + dt f(t, y)
+                if constexpr (P) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+                }
+            } else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) {  // y + dt f(t + dt/2, y + f(t, y) dt/2)
+                if (st == 0) {
+                    ti = ta + dt / 2;
+                    if constexpr (P) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) yi[c] = y[c] + k[c] * (dt / 2);
+                    }
+                } else {
+                    if constexpr (P) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+                    }
+                }
+            } else if (st == 0) {                              // the 3/8 rule
+                ti = ta + dt / 3;
+                if constexpr (P) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { k1[c] = k[c]; yi[c] = y[c] + dt * k[c] / 3; }
+                }
+            } else if (st == 1) {
+                ti = ta + dt * 2 / 3;
+                if constexpr (P) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { k2[c] = k[c]; yi[c] = y[c] + dt * (k1[c] / -3 + k[c]); }
+                }
+            } else if (st == 2) {
+                ti = ta + dt;
+                if constexpr (P) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { k3[c] = k[c]; yi[c] = y[c] + dt * (k1[c] - k2[c] + k[c]); }
+                }
+            } else {
+                if constexpr (P) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) y[c] = y[c] + (k1[c] + 3 * k2[c] + 3 * k3[c] + k[c]) * (dt / 8);
+                }
+            }
+        }
+    }
+    if (P && status == 0 && counted) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) a.grad_x[row * D + m] = y[D + 1 + m];
+        a.grad_logp0[row] = al;
+    }
+    if constexpr (TW) {
+        if constexpr (T) store_total_regs<D>(acc, slab, lane, w, part);
+    } else {
+        commit_step_split<D>(sb, acc, slab, tid, true, part);   // stores (first = true): the slab need not be zero
+    }
+    };   // run
+    if constexpr (!TW) {
+        run(std::integral_constant<int, 0>{});
+    } else {
+        if (wv < kNW) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+    }
+    const int nrun = nst * n_steps;
+    write_stats_global(a.stats, status, nrun, n_steps, 0, nrun, 0.f, a.rows, tid);
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------------
 #if CNF_SPLIT_PART == 2
 // One wave's share of a parameter's column of slabs: g = wv, wv + 4, ... added in that order.  The slabs were written by
@@ -1844,6 +2016,25 @@ hipError_t launch_split_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
     return hipErrorNotSupported;
 }
 
+// fixed-grid solves with one tile per workgroup (kFixedSplitNote, cnf_split_fwd_tw.h): d <= 2, any grid size -- no
+// grid-wide reduction, so nothing has to be co-resident
+template <int D, bool HUTCH>
+static hipError_t split_fixed_fwd_t(const SolveArgs& a, hipStream_t s) {
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    constexpr int NH = (CNF_FWD_HELPER_GROUPS != 0 && !HUTCH) ? D : 1;
+    dbg_timing_begin(s);
+    hipLaunchKernelGGL((fixed_split_tw_kernel<D, HUTCH, NH>), dim3(grid), dim3((1 + NH) * kThreads), 0, s, a);
+    dbg_timing_end(s);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_fixed_fwd(int D, bool hutch, const SolveArgs& a, hipStream_t s) {
+    if (D == 1 && !hutch) return split_fixed_fwd_t<1, false>(a, s);
+    if (D == 2 && !hutch) return split_fixed_fwd_t<2, false>(a, s);
+    if (D == 2 && hutch) return split_fixed_fwd_t<2, true>(a, s);
+    return hipErrorNotSupported;
+}
+
 #endif   // CNF_SPLIT_PART == 1
 #if CNF_SPLIT_PART == 2
 template <int D, bool HUTCH>
@@ -1884,6 +2075,31 @@ hipError_t launch_split_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s
         const uintptr_t al = (uintptr_t)a.x | (uintptr_t)a.e | (uintptr_t)a.grad_z1 | (uintptr_t)a.grad_x | (uintptr_t)a.params;
         return (al & 15) == 0 ? launch_split16_bwd(a, s) : split_bwd_t<16, true>(a, s);
     }
+    return hipErrorNotSupported;
+}
+
+// fixed-grid adjoint with one tile per workgroup (fixed_bwd_split_kernel): d <= 2; a.spread selects the eight-wave,
+// two-workgroups-per-tile launch.  The slabs are stored, not added to: the workspace need not be cleared.
+template <int D, bool HUTCH>
+static hipError_t split_fixed_bwd_t(const SolveArgs& a, hipStream_t s) {
+    const int grid = (int)((a.rows + kRows - 1) / kRows);
+    dbg_timing_begin(s);
+    if (a.spread && kThetaWaves) hipLaunchKernelGGL((fixed_bwd_split_kernel<D, HUTCH, true>), dim3(2 * grid), dim3(2 * kThreads), 0, s, a);
+    else hipLaunchKernelGGL((fixed_bwd_split_kernel<D, HUTCH, false>), dim3(grid), dim3(kThreads), 0, s, a);
+    dbg_timing_end(s);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    if (a.keep_slabs) return hipSuccess;   // cnf_solve_bwd_train: launch_adam_slabs sums them
+    const ParamLayout L = make_layout(D, kH);
+    hipLaunchKernelGGL(reduce_slab_split_kernel, dim3((L.total + 63) / 64), dim3(256), 0, s, a.slab, grid, L.total, a.grad_params,
+                       (a.spread && kThetaWaves) ? L.w(2) : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_fixed_bwd(int D, bool hutch, const SolveArgs& a, hipStream_t s) {
+    if (D == 1 && !hutch) return split_fixed_bwd_t<1, false>(a, s);
+    if (D == 2 && !hutch) return split_fixed_bwd_t<2, false>(a, s);
+    if (D == 2 && hutch) return split_fixed_bwd_t<2, true>(a, s);
     return hipErrorNotSupported;
 }
 

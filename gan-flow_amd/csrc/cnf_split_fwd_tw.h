@@ -569,4 +569,155 @@ __global__ __launch_bounds__((1 + NH) * kThreads) void dopri5_split_tw_kernel(So
     else run(std::integral_constant<int, 2>{});
 }
 
+// ---- the fixed-grid solves (euler / midpoint / rk4 = the 3/8 rule) on the same roles (kFixedSplitNote) ---------------------
+// rk4_kernel (cnf_fwd.hip) is the throughput design: one wave per tile, 32 workgroups at the training batch size.  This is
+// its latency design for batches of up to 16 * 256 rows: one tile per workgroup, the evaluation of dopri5_split_tw_kernel
+// (fwd_eval_tw: value stream on the producers, tangent streams and log p on the helpers one barrier interval behind) inside
+// rk4_kernel's loop -- same grid (points i * step_size + t0, the last clipped to t1), same stage states and the same update
+// expressions, so z and log p differ from rk4_kernel's only by the hidden layers' arithmetic (three-piece bf16 products
+// summed in fp32 against the fp32 MFMA's chain: ~1e-7 relative per evaluation).  No step control, hence no grid-wide
+// reduction and no granules: workgroups are independent.  The helpers receive the divergence of stage s while stage s + 1
+// is evaluated; the step's last stage is drained (one more barrier per step), because log p's update needs it.
+template <int D, bool HUTCH, int NH>
+__global__ __launch_bounds__((1 + NH) * kThreads) void fixed_split_tw_kernel(SolveArgs a) {
+    constexpr int NTHREADS = (1 + NH) * kThreads;
+    constexpr int NSH = (HUTCH ? 1 : D) / NH;   // tangent streams per helper group
+    static_assert(NH == 1 || (!HUTCH && NH == D), "one helper group, or one per tangent stream");
+    const float res = a.residual ? 1.f : 0.f;   // CNF_DIV_RESIDUAL: dynamics f(z) - z
+    __shared__ NetLdsSmall<D> net;
+    __shared__ SplitWaveLds<1> wl[kNW];
+    __shared__ FwdTwLds<D, HUTCH> xc;
+    __shared__ SplitWeightsShare wshare;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = wv & (kNW - 1);
+    const long row = (long)blockIdx.x * kRows + j;
+    const bool in_rows = row < a.rows && lane < 16;
+    const long rr = row < a.rows ? row : a.rows - 1;
+    float zin[D], ee[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+        zin[m] = a.x[rr * D + m];
+        ee[m] = HUTCH ? a.e[rr * D + m] : 0.f;
+    }
+    const float lp_in = a.logp0 ? a.logp0[rr] : 0.f;
+    const int status = a.after ? a.after->status : 0;   // CnfSolverOpts.after: the solve whose output this one consumes failed
+    SplitWeightsB16 wb;
+    convert_weights_b16_shared<D, 1 + NH>(wshare, a.params, tile, wv / kNW, lane);
+    const int s0 = NH > 1 && wv >= kNW ? (wv / kNW - 1) * NSH : 0;
+    stage_net_vectors<D>(net, a.params, tid, NTHREADS);
+    __syncthreads();
+    collect_weights_b16_shared(wb, wshare, tile, lane);
+
+    const int nst = a.fixed_kind == CNF_SOLVER_EULER ? 1 : (a.fixed_kind == CNF_SOLVER_MIDPOINT ? 2 : 4);
+    const int n_steps = status == 0 ? a.n_grid : 0;
+
+    auto run = [&](auto role_c) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr bool P = ROLE == 1, H = ROLE == 2;
+    constexpr int C = P ? D : 1;   // this role's components of the state: producers z, helpers log p
+    const bool counted = in_rows && wv == (P ? 0 : kNW);
+    SplitWaveLds<1>& ws = wl[tile];
+    float y[C], yi[C], k1[C], k2[C], k3[C];
+    if constexpr (P) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) y[m] = zin[m];
+    } else {
+        y[0] = lp_in;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) k1[c] = k2[c] = k3[c] = 0.f;
+    const float sgn = a.t1 >= a.t0 ? 1.f : -1.f;
+    const float tau0 = sgn * a.t0, tau1 = sgn * a.t1;
+    FwdTwPending<D> pend;
+    Prof pr;
+
+    for (int step = 0; step < n_steps; ++step) {
+        // grid point i = i*step_size + tau0 (product rounded before the add, like arange()*h + t0): rk4_kernel's arithmetic
+        const float ta = a.n_grid == 1 ? tau0 : __fadd_rn(__fmul_rn((float)step, a.step_size), tau0);
+        const float tb = (step + 1 == a.n_grid) ? tau1 : __fadd_rn(__fmul_rn((float)(step + 1), a.step_size), tau0);
+        const float dt = tb - ta;
+        float ti = ta;
+#pragma unroll
+        for (int c = 0; c < C; ++c) yi[c] = y[c];
+        for (int st = 0; st < nst; ++st) {
+            float zz[D], f[D], k[C], div_prev = 0.f;
+#pragma unroll
+            for (int m = 0; m < D; ++m) zz[m] = f[m] = 0.f;   // the helpers read neither
+            if constexpr (P) {
+#pragma unroll
+                for (int m = 0; m < D; ++m) zz[m] = yi[m];
+            }
+            fwd_eval_tw<D, HUTCH, ROLE, NSH>(net, wb, ws, xc, lane, tile, s0, sgn * ti, zz, ee, f, pend, div_prev, pr);
+            if constexpr (H) {
+                // the divergence that has just arrived belongs to the PREVIOUS evaluation: stage st - 1 of this step
+                const float kp = -sgn * (div_prev - res * (float)D);
+                if (st == 1) k1[0] = kp;
+                else if (st == 2) k2[0] = kp;
+                else if (st == 3) k3[0] = kp;
+            }
+            const bool last = st + 1 == nst;   // log p's update needs this evaluation's divergence: drain (uniform)
+            if (last) {
+                fwd_tw_drain<D, HUTCH, ROLE, NSH>(net, wb, xc, lane, tile, s0, ee, pend, div_prev);
+                if constexpr (H) k[0] = -sgn * (div_prev - res * (float)D);
+            }
+            if constexpr (P) {
+#pragma unroll
+                for (int m = 0; m < D; ++m) k[m] = sgn * fmaf(-res, zz[m], f[m]);
+            }
+            // rk4_kernel's updates; the helpers form no stage states of log p (nothing reads them), only the step's sum
+            if (a.fixed_kind == CNF_SOLVER_EULER) {            // y + dt f(t, y)
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+            } else if (a.fixed_kind == CNF_SOLVER_MIDPOINT) {  // y + dt f(t + dt/2, y + f(t, y) dt/2)
+                if (st == 0) {
+                    ti = ta + dt / 2;
+                    if constexpr (P) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) yi[c] = y[c] + k[c] * dt / 2;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) y[c] = y[c] + dt * k[c];
+                }
+            } else if (st == 0) {
+                ti = ta + dt / 3;
+                if constexpr (P) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { k1[c] = k[c]; yi[c] = y[c] + dt * k[c] / 3; }
+                }
+            } else if (st == 1) {
+                ti = ta + dt * 2 / 3;
+                if constexpr (P) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { k2[c] = k[c]; yi[c] = y[c] + dt * (k1[c] / -3 + k[c]); }
+                }
+            } else if (st == 2) {
+                ti = ta + dt;
+                if constexpr (P) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { k3[c] = k[c]; yi[c] = y[c] + dt * (k1[c] - k2[c] + k[c]); }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) y[c] = y[c] + (k1[c] + 3 * k2[c] + 3 * k3[c] + k[c]) * (dt / 8);
+            }
+        }
+    }
+    if (status == 0 && counted) {
+        if constexpr (P) {
+#pragma unroll
+            for (int m = 0; m < D; ++m) a.z_out[row * D + m] = y[m];
+        } else {
+            a.logp_out[row] = y[0];
+        }
+    }
+    };   // run
+    if (wv < kNW) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
+    // counters as rk4_kernel reports them (the API layer zeroes the block before a fixed-grid launch)
+    const int nrun = nst * n_steps;
+    write_stats_global(a.stats, status, nrun, n_steps, 0, nrun, 0.f, a.rows, tid);
+}
+
 }  // namespace cnf

@@ -285,9 +285,12 @@ class FusedTrainStep:
         # the tail: cnf_solve_bwd_train (adjoint + slab sum + Adam in two kernels; for the last block also the loss and its
         # cotangents) where it is built -- hidden width 64, <= 4096 rows -- else cnf_nll_loss, cnf_solve_bwd, cnf_adam_step
         last = len(self.blocks) - 1
-        fused = [self.fuse_tail and tape[i][0].hidden == 64 and z.shape[0] <= 4096 for i in range(last + 1)]
+        # (fixed-grid solvers: cnf_solve_bwd_train takes the loss kernel's cotangents, at dim <= 2)
+        fixed = [tape[i][3].solver != 0 for i in range(last + 1)]
+        fused = [self.fuse_tail and tape[i][0].hidden == 64 and z.shape[0] <= 4096 and not (fixed[i] and tape[i][0].dim > 2)
+                 for i in range(last + 1)]
         loss = gz = gl = None
-        if not fused[last]:
+        if not fused[last] or fixed[last]:
             loss, gz, gl = nat.nll_loss(z, lp)
         for i in range(last, -1, -1):
             net, t0, t1, opts, e, z1, lp1 = tape[i]
@@ -528,10 +531,9 @@ def main(argv=None):
         if args.fused or args.graphed:
             logger.info("regularised dynamics train through the eager autograd + torch.optim.Adam loop")
         args.fused = args.graphed = 0
-    if args.fused and (args.layer_type != "concatsquash" or args.batch_norm or any(n.is_padded() for n in odenets)
-                       or args.solver != "dopri5"):
+    if args.fused and (args.layer_type != "concatsquash" or args.batch_norm or any(n.is_padded() for n in odenets)):
         logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of concatsquash CNF blocks of hidden "
-                    "width 64 / 256 trained with dopri5 only; fixed-grid solvers train through cnf_solve_bwd's fixed-grid adjoint)")
+                    "width 64 / 256)")
         args.fused = 0
     for block in model.chain:
         if isinstance(block, CNF):

@@ -89,7 +89,12 @@ enum { CNF_FLAG_CLEAN = 1, CNF_FLAG_SPREAD = 2, CNF_FLAG_ADJ_CONTROL_ALL = 4, CN
  * streams of its feature tile) instead of the eight-wave one (value stream on four waves, tangent streams and log p on the
  * second wave of each SIMD, one barrier interval behind; twelve waves -- a helper group per tangent stream -- at dim 2 with
  * the exact divergence).  Same arithmetic, identical bits; for A/B timing and the test
- * that holds the two kernels to each other.  Ignored where the eight-wave kernel does not apply.                        */
+ * that holds the two kernels to each other.  Ignored where the eight-wave kernel does not apply.
+ * Fixed-grid solvers (CNF_SOLVER_RK4 | EULER | MIDPOINT; cnf_solve_fwd, cnf_solve_fwd_static, cnf_solve_bwd), hidden width 64,
+ * dim <= 2, at most 4096 rows: such solves run one 16-row tile per WORKGROUP (the feature-split evaluations of the dopri5
+ * kernels on the fixed grid: 4-6x shorter than one wave per tile at the training batch size; the adjoint with
+ * CNF_FLAG_SPREAD on two eight-wave workgroups per tile); the flag keeps the one-wave-per-tile kernels that larger batches
+ * use (same grid and step counts; results equal up to the hidden layers' arithmetic, ~1e-7 relative per evaluation).     */
 
 /* CNF_FLAG_SPREAD (cnf_solve_bwd, at most half as many 16-row tiles as the device has
  * compute units -- 2048 rows on an MI355X; ignored otherwise): the adjoint runs TWO workgroups per tile.  Both
@@ -282,7 +287,9 @@ int cnf_adam_step(float *params, const float *grad, float *exp_avg, float *exp_a
  *   - grad_params may be NULL (the summed gradient is then not stored anywhere).
  * `params` is updated in place AFTER the solve has read it -- unless the adjoint solve ended with a non-zero status
  * (its own failure, or one inherited through opts->after): then the update kernel changes nothing.
- * Hidden width 64, at most 4096 rows; otherwise the call fails and the three separate entry points are to be used.  */
+ * Hidden width 64, at most 4096 rows; otherwise the call fails and the three separate entry points are to be used.
+ * Fixed-grid solvers: dim <= 2 and explicit cotangents only (grad_z1 / grad_logp1 from cnf_nll_loss; the in-kernel loss
+ * rides on a grid-wide reduction of the dopri5 controller, which a fixed grid does not have).                          */
 int cnf_solve_bwd_train(const CnfNetDesc *net, float *params, const float *z1, const float *logp1,
                         const float *e, const float *grad_z1, const float *grad_logp1, int64_t rows,
                         float t0, float t1, const CnfSolverOpts *opts, float *grad_x, float *grad_logp0,

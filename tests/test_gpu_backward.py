@@ -844,6 +844,64 @@ def test_fixed_grid_adjoint_other_kernel_families(solver, dim, hidden, hutch, ro
     assert e_gp < 5e-5 and e_gx < 5e-5
 
 
+@pytest.mark.parametrize("solver", ["rk4", "euler", "midpoint"])
+@pytest.mark.parametrize("case", ["d2", "d2_ragged", "d1", "d2_hutch", "d2_residual_reverse", "d2_one_step", "stiff_d1"])
+def test_fixed_grid_one_tile_per_workgroup_kernels(solver, case):
+    """Fixed-grid solves of up to 4096 rows run one tile per WORKGROUP (fixed_split_tw_kernel, csrc/cnf_split_fwd_tw.h;
+    fixed_bwd_split_kernel, csrc/cnf_split.hip: the feature-split evaluations of the dopri5 kernels inside rk4_kernel's /
+    fixed_bwd_kernel's loops).  Held here against the one-wave-per-tile kernels (CNF_FLAG_FWD_FOUR_WAVES keeps them for such
+    batches), which test_fixed_grid_adjoint_matches_oracle's 5000-row case and test_rk4_parity_* hold against the oracle: same
+    grid and step counts; states and gradients equal up to the hidden layers' arithmetic (three-piece bf16 products summed in
+    fp32 against the fp32 MFMA chain).  The adjoint in both of its launches: four waves per tile, and CNF_FLAG_SPREAD's two
+    eight-wave workgroups per tile, whose sums must equal the four-wave launch's exactly in the matrices' halves each keeps."""
+    nat = _native()
+    g = torch.Generator().manual_seed(23)
+    dim = 1 if "d1" in case else 2
+    hutch = "hutch" in case
+    rows = {"d2": 2048, "d2_ragged": 203, "d1": 4096, "d2_hutch": 500, "d2_residual_reverse": 777, "d2_one_step": 64, "stiff_d1": 96}[case]
+    if case == "stiff_d1":
+        m = oracle_fixture_model("multimodal")
+        x = torch.rand(rows, 1, generator=g) * 76.0 + 7.0
+        step = {"rk4": 0.004, "midpoint": 0.002, "euler": 0.001}[solver]
+    else:
+        m = oracle_random_model(dim, seed=19, divergence_fn="approximate" if hutch else "brute_force", scale=1.5)
+        x = torch.randn(rows, dim, generator=g) * 1.2
+        step = None if case == "d2_one_step" else 0.07
+    net = nat.net_desc(dim, 64, 3, hutch, residual="residual" in case)
+    params = _flat(m).to(DEV)
+    x = x.to(DEV)
+    e = torch.randn(rows, dim, generator=g).to(DEV) if hutch else None
+    t0, t1 = (0.5, 0.0) if "reverse" in case else (0.0, 0.5)
+    gz = torch.randn(rows, dim, generator=g).to(DEV) / rows
+    gl = torch.randn(rows, 1, generator=g).to(DEV) / rows
+    out = {}
+    for name, flags in (("split", 0), ("spread", nat.FLAG_SPREAD), ("wave", nat.FLAG_FWD_FOUR_WAVES)):
+        opts = nat.make_opts(solver, step_size=step, flags=flags)
+        z, lp, st = nat.solve_fwd(net, params, x, None, t0, t1, opts, e)
+        gx, glp, gp, stb = nat.solve_bwd(net, params, z, lp, gz, gl, t0, t1, opts, e)
+        torch.cuda.synchronize()
+        st, stb = nat.Stats(st), nat.Stats(stb)
+        st.raise_for_status()
+        stb.raise_for_status()
+        out[name] = (z.clone(), lp.clone(), gx.clone(), glp.clone(), gp.clone(),
+                     (st.nfe, st.n_accepted, st.evals_run, stb.nfe, stb.n_accepted, stb.evals_run))
+    per_step = {"rk4": 4, "euler": 1, "midpoint": 2}[solver]
+    n_steps = out["wave"][5][1]
+    assert out["split"][5] == out["wave"][5] == out["spread"][5] == (per_step * n_steps, n_steps, per_step * n_steps) * 2
+    assert n_steps == 1 if step is None else n_steps >= 7
+    # the forward solve does not depend on the adjoint's launch shape; the state half of the adjoint up to rounding at most
+    assert torch.equal(out["split"][0], out["spread"][0]) and torch.equal(out["split"][1], out["spread"][1])
+    assert rel_err(out["spread"][2], out["split"][2]) < 1e-6 and torch.equal(out["split"][3], out["spread"][3])
+    errs = [rel_err(out["split"][i], out["wave"][i]) for i in range(5)]
+    e_sp = rel_err(out["spread"][4], out["split"][4])
+    print("%s %s rows=%d steps=%d: split vs one-wave-per-tile z %.1e logp %.1e grad_x %.1e grad_logp %.1e grad_theta %.1e | spread vs split grad_theta %.1e"
+          % (solver, case, rows, n_steps, *errs, e_sp))
+    bar = 2e-4 if case == "stiff_d1" else 5e-6   # the stiff field amplifies rounding differences over its 125..500 steps
+    assert errs[0] < bar and errs[1] < bar and errs[2] < 4 * bar and errs[4] < 4 * bar
+    assert torch.equal(out["split"][3], out["wave"][3])   # a_logp is constant
+    assert e_sp < 1e-6
+
+
 def test_fixed_grid_adjoint_limits():
     """What the fixed-grid adjoint does not cover is refused with a message, before anything is launched."""
     nat = _native()

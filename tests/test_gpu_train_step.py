@@ -113,6 +113,59 @@ def test_fused_train_step_matches_autograd_loop(graph, blocks):
     assert model.chain[0].num_evals() > 0
 
 
+@pytest.mark.parametrize("solver,step_size,graph,blocks", [("rk4", 0.05, True, 1), ("rk4", 0.125, False, 2), ("midpoint", 0.05, True, 1),
+                                                           ("euler", None, False, 1)])
+def test_fused_train_step_fixed_grid_matches_autograd_loop(solver, step_size, graph, blocks):
+    """`--solver rk4 | midpoint | euler` through FusedTrainStep: the one-tile-per-workgroup fixed-grid kernels
+    (fixed_split_tw_kernel, fixed_bwd_split_kernel with CNF_FLAG_SPREAD), cnf_nll_loss for the cotangents and
+    cnf_solve_bwd_train's slab sum + Adam.  Same batches and initial weights as the autograd + torch.optim.Adam loop over the
+    same solves: same trajectory to rounding; and the two-kernel tail (fuse_tail) gives the bits of cnf_solve_bwd +
+    cnf_adam_step."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    data = make_gu(8, seed=3)
+    batches = [data.get_sample(2048).to(DEV) for _ in range(6)]
+
+    def build():
+        torch.manual_seed(5)
+        m = gu_ffjord.build_model(2, num_blocks=blocks, solver=solver).to(DEV).train()
+        for blk in m.chain:
+            blk.solver_options = {"step_size": step_size} if step_size else {}
+            blk.spread_adjoint = True
+        return m
+
+    ref = build()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-5)
+    ref_losses = []
+    for x in batches:
+        opt.zero_grad(set_to_none=True)
+        loss = gu_ffjord.compute_loss(ref, x)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    nfe_ref = (sum(b.last_stats["forward"].nfe for b in ref.chain), sum(b.last_stats["backward"].nfe for b in ref.chain))
+    runs = []
+    for fuse in (True, False):
+        model = build()
+        step = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=graph and fuse, fuse_tail=fuse)
+        losses = [step(x).item() for x in batches]
+        nfe = step.check()
+        runs.append((losses, [f.clone() for f in step.flats], [m.clone() for m in step.exp_avg]))
+        assert step.step_count == len(batches) and nfe == nfe_ref
+    losses, flats, _ = runs[0]
+    print("reference", ["%.5f" % v for v in ref_losses])
+    print("fused    ", ["%.5f" % v for v in losses])
+    per_step = {"rk4": 4, "euler": 1, "midpoint": 2}[solver]
+    assert nfe_ref[0] % (per_step * blocks) == 0 and nfe_ref[0] == nfe_ref[1]
+    assert all(abs(a - b) <= 2e-5 * abs(a) for a, b in zip(ref_losses, losses))
+    pr = torch.cat([p.detach().reshape(-1) for p in ref.parameters() if p.requires_grad])
+    pf = torch.cat([p.detach().reshape(-1) for p in model.parameters() if p.requires_grad])
+    assert (pr - pf).abs().max().item() < 5e-5
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1] + runs[0][2], runs[1][1] + runs[1][2]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dim,blocks,rows,div", [(2, 1, 2048, "brute_force"), (2, 2, 1000, "brute_force"), (1, 1, 77, "brute_force"),
                                                  (16, 1, 2048, "approximate"), (2, 1, 300, "approximate")])
 def test_solve_bwd_train_equals_separate_calls(dim, blocks, rows, div):
