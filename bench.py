@@ -50,7 +50,7 @@ def parse():
                         "iteration); graph: autograd + torch.optim.Adam loop captured as one hipGraph; eager: that loop, launched eagerly")
     p.add_argument("--extras", type=str, default="roofline,late,eval,d16,wide,rk4,pair,cpu,config1,repeats",
                    help="comma list of the additional measurements to run: roofline, late, eval, d16, wide, pair, cpu, config1, "
-                        "repeats ('' = none)")
+                        "rk4, repeats ('' = none)")
     p.add_argument("--repeats", type=int, default=5, help="extra repeats of the timed loop (fresh seed-1 model each) for the spread keys")
     p.add_argument("--cpu-late-iters", type=int, default=2,
                    help="CPU-oracle iterations on the late_training field (tens of seconds each; 0 = skip)")
