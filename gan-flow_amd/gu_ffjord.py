@@ -480,6 +480,11 @@ def parse_args(argv=None):
     p.add_argument("--atol", type=float, default=1e-5)
     p.add_argument("--rtol", type=float, default=1e-5)
     p.add_argument("--step_size", type=float, default=None)
+    # ffjord/train_misc.py::set_cnf_options: what evaluation-mode solves use (default: the training solver / tolerances)
+    p.add_argument("--test_solver", type=str, default=None, choices=["dopri5", "rk4", "euler", "midpoint"])
+    p.add_argument("--test_atol", type=float, default=None)
+    p.add_argument("--test_rtol", type=float, default=None)
+    p.add_argument("--rademacher", type=eval, default=False, choices=[True, False], help="Hutchinson probe: Rademacher instead of Gaussian")
     p.add_argument("--adjoint_error_control", type=str, default="state_only", choices=["state_only", "all"],
                    help="which tensors of the adjoint state steer the backward solve: (z, logp) as the reference's length-2 "
                         "tolerance lists do (default), or the per-row adjoints as well (CNF_FLAG_ADJ_CONTROL_ALL; not in the reference)")
@@ -522,7 +527,7 @@ def main(argv=None):
             reg_coeffs.append(coeff)
     model = build_model(2, tuple(int(d) for d in args.dims.split("-")), args.num_blocks, args.time_length, args.train_T,
                         args.divergence_fn, args.solver, args.atol, args.rtol, layer_type=args.layer_type,
-                        residual=args.residual, batch_norm=args.batch_norm, bn_lag=args.bn_lag,
+                        residual=args.residual, batch_norm=args.batch_norm, bn_lag=args.bn_lag, rademacher=args.rademacher,
                         nonlinearity=args.nonlinearity, regularization_fns=tuple(reg_fns)).to(device)
     odenets = [blk.odefunc.odefunc.diffeq for blk in model.chain if isinstance(blk, CNF)]
     if reg_fns:
@@ -538,6 +543,9 @@ def main(argv=None):
     for block in model.chain:
         if isinstance(block, CNF):
             block.adjoint_error_control = args.adjoint_error_control
+            block.test_solver = args.test_solver if args.test_solver else args.solver
+            block.test_atol = args.test_atol if args.test_atol else args.atol
+            block.test_rtol = args.test_rtol if args.test_rtol else args.rtol
             if args.step_size:
                 block.solver_options["step_size"] = args.step_size
     logger.info("parameters: %d" % count_parameters(model))

@@ -241,3 +241,30 @@ def test_driver_trains_with_kinetic_regularisers(tmp_path):
     (nll + reg).backward()
     net = model.chain[0].odefunc.odefunc.diffeq   # (sqrt_end_time never trains: the reference detaches the end time)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in net.parameters())
+
+
+@pytest.mark.gpu
+def test_driver_trains_with_a_fixed_grid_solver_and_test_solver_flags(tmp_path, monkeypatch):
+    """`gu_maf --solver rk4 --step_size h` trains through FusedTrainStep (the one-tile-per-workgroup fixed-grid kernels in one
+    captured graph) and `--test_solver / --test_atol / --test_rtol` (ffjord/train_misc.py::set_cnf_options) reach the blocks'
+    evaluation-mode solves: the logged evaluation runs dopri5 at the test tolerances while training runs rk4."""
+    from gan_flow_amd import gu_ffjord
+    made = []
+    orig = gu_ffjord.FusedTrainStep.__init__
+
+    def recording(self, model, *a, **k):
+        made.append(model)
+        return orig(self, model, *a, **k)
+
+    monkeypatch.setattr(gu_ffjord.FusedTrainStep, "__init__", recording)
+    gu_ffjord.main(["--gu_num", "8", "--batch_size", "512", "--log_interval", "2", "--eval_size", "2000", "--eval_logp_size", "512",
+                    "--save", str(tmp_path), "--niters", "4", "--solver", "rk4", "--step_size", "0.1", "--test_solver", "dopri5",
+                    "--test_atol", "1e-4", "--test_rtol", "1e-4"])
+    assert len(made) == 1                                   # the fused step took the fixed-grid configuration
+    blk = made[0].chain[0]
+    assert (blk.solver, blk.test_solver, blk.test_atol, blk.test_rtol) == ("rk4", "dopri5", 1e-4, 1e-4)
+    assert blk.solver_options == {"step_size": 0.1}
+    sd = torch.load(tmp_path / "ffjord_state_dict.pth", map_location="cpu", weights_only=True)
+    torch.manual_seed(1)
+    fresh = gu_ffjord.build_model(2, solver="rk4")
+    assert max((sd[k] - v).abs().max().item() for k, v in fresh.state_dict().items()) > 1e-4
