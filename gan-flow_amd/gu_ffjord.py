@@ -213,6 +213,9 @@ class FusedTrainStep:
                 raise NotImplementedError("FusedTrainStep handles a SequentialFlow of CNF blocks without regularisers")
         self.nets = [_inner(blk.odefunc).diffeq for blk in self.blocks]
         self.flats = [net.flatten_parameters() for net in self.nets]
+        # entries of the flat buffers that are not parameters (zero padding of narrower nets, the constants of the 'ignore' /
+        # 'concat_v2' / 'squash' layer types): restored after every update, one index_copy_ per block in the captured graph
+        self.consts = [net.flat_constants for net in self.nets]
         self.exp_avg = [torch.zeros_like(f) for f in self.flats]
         self.exp_avg_sq = [torch.zeros_like(f) for f in self.flats]
         dev = example_batch.device
@@ -304,6 +307,8 @@ class FusedTrainStep:
                 gz, gl, gp, prev = nat.solve_bwd(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, e, stats=self.stats[i, 1],
                                                  workspace=self.workspace)
                 nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], guard=prev, **self.hyper)
+            if self.consts[i] is not None:
+                self.flats[i].index_copy_(0, *self.consts[i])
         return loss
 
     def __call__(self, x=None):
@@ -536,9 +541,9 @@ def main(argv=None):
         if args.fused or args.graphed:
             logger.info("regularised dynamics train through the eager autograd + torch.optim.Adam loop")
         args.fused = args.graphed = 0
-    if args.fused and (args.layer_type != "concatsquash" or args.batch_norm or any(n.is_padded() for n in odenets)):
-        logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of concatsquash CNF blocks of hidden "
-                    "width 64 / 256)")
+    if args.fused and (args.layer_type in ("concat", "concatcoord") or args.batch_norm):
+        logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of CNF blocks whose parameters have places "
+                    "of their own in the kernels' layout: not 'concat' layers, no batch norm between blocks)")
         args.fused = 0
     for block in model.chain:
         if isinstance(block, CNF):

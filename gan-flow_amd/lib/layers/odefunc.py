@@ -84,33 +84,57 @@ class ODEnet(nn.Module):
         return torch.cat(parts)
 
     def flatten_parameters(self):
-        """Move the parameters into ONE contiguous buffer laid out as the kernels read it and make every
-        nn.Parameter a view of its slice (names, shapes and state_dict are unchanged).  Returns the buffer: an update
-        written to it (gu_ffjord.FusedTrainStep) is an update of the module's parameters.  `.to()` / `.cuda()` /
+        """Move the parameters into ONE contiguous buffer laid out as the kernels read it (flat_parameters(): per layer W, b,
+        w_hb, w_g, b_g, hidden widths zero-padded to kernel_hidden()) and make every nn.Parameter a view of its place in it
+        (names, shapes and state_dict are unchanged; a padded weight is the top-left block of its kernel-width matrix, a
+        strided view).  Returns the buffer: an update written to it (gu_ffjord.FusedTrainStep) is an update of the module's
+        parameters.  What the buffer holds beside parameters -- the zero padding, and the constants by which 'ignore',
+        'concat_v2' and 'squash' layers present themselves as concatsquash (basic.py) -- is listed in self.flat_constants
+        = (index, value) or None: an in-place optimizer must restore those entries after every step (FusedTrainStep does;
+        padded features of a softplus net, for one, have non-zero gradients).  `.to()` / `.cuda()` /
         load_state_dict(assign=True) re-allocate parameters: call again afterwards (flat_is_current() tells)."""
-        if self.layer_type != "concatsquash" or self.is_padded():
-            raise NotImplementedError("flatten_parameters (and FusedTrainStep) need layer_type='concatsquash' and hidden widths "
-                                      "64 or 256: other layer types and padded widths present constants to the kernels that "
-                                      "an in-place optimizer must not touch (train them through autograd: GraphedTrainStep)")
-        ps = list(self.parameters())
-        flat = torch.cat([p.detach().reshape(-1) for p in ps])
-        off = 0
-        for p in ps:
-            n = p.numel()
-            p.data = flat[off:off + n].view(p.shape)
-            off += n
-        self._flat = flat
+        if self.layer_type in ("concat", "concatcoord"):
+            raise NotImplementedError("flatten_parameters (and FusedTrainStep): a 'concat' layer keeps the time column inside "
+                                      "its weight matrix, which is two separate blocks of the kernels' layout; train it through "
+                                      "autograd (GraphedTrainStep)")
+        flat = self.flat_parameters().detach().clone()
+        is_const = torch.ones(flat.numel(), dtype=torch.bool, device=flat.device)
+        hk, last, off, views = self.kernel_hidden(), len(self.layers) - 1, 0, []
+        for i, layer in enumerate(self.layers):
+            slots = layer.kernel_slices()
+            real = {id(q) for q in layer.parameters()}
+            n_in, n_out = layer.dim_in, layer.dim_out
+            k_in = n_in if i == 0 else hk
+            k_out = n_out if i == last else hk
+            w = slots[0]
+            if id(w) in real:
+                view = flat[off:off + k_out * k_in].view(k_out, k_in)[:n_out, :n_in]
+                is_const[off:off + k_out * k_in].view(k_out, k_in)[:n_out, :n_in] = False
+                views.append((w, view))
+            off += k_out * k_in
+            for v in slots[1:]:
+                if id(v) in real:
+                    view = flat[off:off + n_out].view(v.shape)
+                    is_const[off:off + n_out] = False
+                    views.append((v, view))
+                off += k_out
+        assert off == flat.numel()
+        if len(views) != sum(1 for _ in self.parameters()):
+            raise NotImplementedError("flatten_parameters: a parameter of this ODEnet has no place of its own in the kernels' layout")
+        for p_, view in views:
+            p_.data = view
+        self._flat, self._flat_views = flat, views
+        idx = torch.nonzero(is_const).reshape(-1)
+        self.flat_constants = (idx, flat[idx].clone()) if idx.numel() else None
         return flat
 
     def flat_is_current(self):
         flat = getattr(self, "_flat", None)
         if flat is None:
             return False
-        addr = flat.data_ptr()
-        for p in self.parameters():
-            if p.data_ptr() != addr or p.device != flat.device:
+        for p_, view in self._flat_views:
+            if p_.data_ptr() != view.data_ptr() or p_.device != flat.device or p_.stride() != view.stride():
                 return False
-            addr += 4 * p.numel()
         return True
 
     def forward(self, t, y):

@@ -113,6 +113,58 @@ def test_fused_train_step_matches_autograd_loop(graph, blocks):
     assert model.chain[0].num_evals() > 0
 
 
+@pytest.mark.parametrize("layer_type,dims,act,graph", [("concatsquash", (32, 48, 32), "tanh", True), ("squash", (64, 64, 64), "tanh", False),
+                                                       ("ignore", (20, 20, 20), "softplus", True), ("concat_v2", (40, 64, 64), "elu", False)])
+def test_fused_train_step_other_layer_types_and_padded_widths(layer_type, dims, act, graph):
+    """FusedTrainStep on nets whose flat kernel buffer holds more than parameters: zero padding (hidden widths below the
+    kernel width) and the constants by which 'ignore' / 'concat_v2' / 'squash' layers present themselves as concatsquash.
+    ODEnet.flatten_parameters() aliases every parameter to its place (a padded weight as a strided block) and lists the rest;
+    the step restores those entries after each update (padded features of a softplus net have non-zero gradients, and weight
+    decay would move the gate-open constant).  Same trajectory as the autograd + torch.optim.Adam loop, which slices the
+    kernels' gradient back to the real parameters."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    data = make_gu(8, seed=3)
+    batches = [data.get_sample(1024).to(DEV) for _ in range(6)]
+
+    def build():
+        torch.manual_seed(7)
+        return gu_ffjord.build_model(2, dims=dims, layer_type=layer_type, nonlinearity=act).to(DEV).train()
+
+    ref = build()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-5)
+    ref_losses = []
+    for x in batches:
+        opt.zero_grad(set_to_none=True)
+        loss = gu_ffjord.compute_loss(ref, x)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    model = build()
+    names = [k for k, _ in model.named_parameters()]
+    step = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=graph)
+    net = model.chain[0].odefunc.odefunc.diffeq
+    consts = net.flat_constants
+    assert consts is not None and consts[0].numel() > 0
+    losses = [step(x).item() for x in batches]
+    step.check()
+    print("reference", ["%.5f" % v for v in ref_losses])
+    print("fused    ", ["%.5f" % v for v in losses])
+    assert all(abs(a - b) <= 2e-5 * abs(a) for a, b in zip(ref_losses, losses))
+    assert [k for k, _ in model.named_parameters()] == names
+    for (k, a), (_, b) in zip(ref.named_parameters(), model.named_parameters()):
+        assert a.shape == b.shape and (a - b).abs().max().item() < 5e-5, k
+    # what is not a parameter is what it was: padding zero, constants constant
+    assert torch.equal(step.flats[0][consts[0]], consts[1])
+    # and the kernels still see the module's parameters: evaluation through the module equals the reference model's
+    model.eval()
+    ref.eval()
+    xe = batches[0][:256]
+    z1, dl1 = model(xe, torch.zeros(256, 1, device=DEV))
+    z2, dl2 = ref(xe, torch.zeros(256, 1, device=DEV))
+    assert rel_err(z1, z2) < 1e-4 and rel_err(dl1, dl2) < 1e-3
+
+
 @pytest.mark.parametrize("solver,step_size,graph,blocks", [("rk4", 0.05, True, 1), ("rk4", 0.125, False, 2), ("midpoint", 0.05, True, 1),
                                                            ("euler", None, False, 1)])
 def test_fused_train_step_fixed_grid_matches_autograd_loop(solver, step_size, graph, blocks):

@@ -444,3 +444,33 @@ def test_eight_wave_kernels_are_free_of_the_packed_fp32_hazard(act, tmp_path):
             assert not hazardous.search(line), (cur, line.strip())
     assert seen_eight_wave >= 3     # d = 1, d = 2 exact, d = 2 Hutchinson
     assert seen_fwd_tw >= 3
+
+
+@pytest.mark.parametrize("layer_type,dims", [("concatsquash", (64, 64, 64)), ("concatsquash", (32, 48, 32)), ("squash", (64, 64, 64)),
+                                             ("ignore", (20, 20, 20)), ("concat_v2", (64, 64, 64)), ("concatsquash", (256, 256, 256))])
+def test_flatten_parameters_aliases_every_parameter_to_its_place(layer_type, dims):
+    """ODEnet.flatten_parameters (host logic, no GPU): the flat buffer is flat_parameters() -- the vector the kernels read --
+    every parameter becomes a view of its place in it (names, shapes, values and state_dict unchanged; padded weights as
+    strided blocks), an update of the buffer is an update of the parameters, and what is not a parameter (zero padding, the
+    constants of the special-case layer types) is listed in flat_constants.  'concat' layers are refused with a message."""
+    from gan_flow_amd.lib.layers.odefunc import ODEnet
+    torch.manual_seed(0)
+    net = ODEnet(dims, (2,), layer_type=layer_type)
+    before = net.flat_parameters().detach().clone()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    flat = net.flatten_parameters()
+    assert torch.equal(flat, before) and net.flat_is_current()
+    assert list(net.state_dict()) == list(sd) and all(torch.equal(sd[k], v) for k, v in net.state_dict().items())
+    assert torch.equal(net.flat_parameters().detach(), flat)
+    flat.add_(1.0)
+    assert all(torch.equal(sd[k] + 1.0, v) for k, v in net.state_dict().items())
+    n_real = sum(p.numel() for p in net.parameters())
+    consts = net.flat_constants
+    assert flat.numel() == n_real + (0 if consts is None else consts[0].numel())
+    assert (consts is None) == (layer_type == "concatsquash" and not net.is_padded())
+    if consts is not None:
+        assert torch.equal(before[consts[0]], consts[1])
+    net.layers[0]._layer.weight.data = net.layers[0]._layer.weight.data.clone()      # what .to() / assign=True do
+    assert not net.flat_is_current()
+    with pytest.raises(NotImplementedError, match="concat"):
+        ODEnet((64, 64, 64), (2,), layer_type="concat").flatten_parameters()
