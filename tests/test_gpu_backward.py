@@ -376,8 +376,11 @@ def test_other_layer_types_run_on_the_same_kernels(layer_type):
     bar = 2e-4 if nfe == nfe_ref else 2e-3
     assert gp.numel() == gp_ref.numel()
     assert rel_err(gp, gp_ref) < bar and rel_err(xp.grad, gx_ref) < bar
-    with pytest.raises(NotImplementedError):
-        gu_ffjord.FusedTrainStep(mp, xp.detach(), graph=False)
+    if layer_type == "concat":   # its time column sits inside the weight matrix: no place of its own in the kernels' layout
+        with pytest.raises(NotImplementedError):
+            gu_ffjord.FusedTrainStep(mp, xp.detach(), graph=False)
+    else:                        # aliased, constants listed (tests/test_gpu_train_step.py trains them)
+        assert gu_ffjord.FusedTrainStep(mp, xp.detach(), graph=False).consts[0] is not None
 
 
 def test_short_training_run_reduces_loss():
@@ -614,8 +617,7 @@ def test_other_hidden_widths_run_zero_padded(hidden):
     assert (st["backward"].n_accepted, st["backward"].n_rejected) == (st_ref["backward"]["n_accepted"], st_ref["backward"]["n_rejected"])
     assert abs(loss.item() - loss_ref) < 1e-4
     assert rel_err(gp, gp_ref) < 2e-4 and rel_err(xp.grad, gx_ref) < 2e-4
-    with pytest.raises(NotImplementedError):
-        gu_ffjord.FusedTrainStep(mp, xp.detach(), graph=False)
+    assert gu_ffjord.FusedTrainStep(mp, xp.detach(), graph=False).consts[0] is not None   # the padding, restored after every update
 
 
 @pytest.mark.parametrize("dim,hidden,hutch,rows", [(2, 64, False, 512), (1, 64, False, 5000), (16, 64, True, 300), (2, 256, False, 200),
