@@ -188,7 +188,7 @@ class FusedTrainStep:
     device until .check()."""
 
     def __init__(self, model, example_batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, graph=True,
-                 warmup_batches=(), spread=True, fuse_tail=True, sampler=None, warmup=0):
+                 warmup_batches=(), spread=True, fuse_tail=True, sampler=None, warmup=0, reg_coeffs=None):
         # sampler: a gu.DeviceSampler (or anything with .fill(tensor)): every iteration starts by drawing its batch on the
         # device straight into the static input (one more kernel in the captured graph, no host sampler, no copy) and
         # step() takes no argument; `warmup` such iterations run before the capture (warmup_batches is for fed batches)
@@ -208,9 +208,16 @@ class FusedTrainStep:
         self._native, self.model = _native, model
         self.hyper = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.blocks = list(model.chain)
+        # reg_coeffs: the weights of the blocks' regularisation states in the loss (`--l1int` / `--l2int`, in the order of the
+        # blocks' regularization_fns): loss = nll + sum over blocks and k of c_k r_k.  Regularised blocks run cnf_solve_fwd_reg /
+        # cnf_solve_bwd_reg (the adjoint of a state is the constant c_k) and cnf_adam_step: library kernels only, capturable
         for blk in self.blocks:
-            if not isinstance(blk, CNF) or blk.nreg:
-                raise NotImplementedError("FusedTrainStep handles a SequentialFlow of CNF blocks without regularisers")
+            if not isinstance(blk, CNF):
+                raise NotImplementedError("FusedTrainStep handles a SequentialFlow of CNF blocks")
+            if blk.nreg and (reg_coeffs is None or len(reg_coeffs) != blk.nreg):
+                raise ValueError("regularised blocks need reg_coeffs, one coefficient per regularisation function (%d)" % blk.nreg)
+        self.reg_coeffs = None if reg_coeffs is None else torch.tensor([float(c) for c in reg_coeffs], dtype=torch.float32,
+                                                                       device=example_batch.device)
         self.nets = [_inner(blk.odefunc).diffeq for blk in self.blocks]
         self.flats = [net.flatten_parameters() for net in self.nets]
         # entries of the flat buffers that are not parameters (zero padding of narrower nets, the constants of the 'ignore' /
@@ -275,30 +282,41 @@ class FusedTrainStep:
         # parameters are never updated from the garbage a failed solve leaves behind
         if self.sampler is not None:
             self.sampler.fill(self.static_x)
-        z, lp, tape, prev = self.static_x, None, [], None
+        z, lp, tape, prev, reg_terms = self.static_x, None, [], None, []
         for i, blk in enumerate(self.blocks):
             net, t0, t1, opts, e = blk.solve_plan(z, reset_counter=False)
             if opts.solver == 0 and opts.tile_rows == 0:
                 opts.flags |= nat.FLAG_CLEAN
             if self.spread:
                 opts.flags |= nat.FLAG_SPREAD
+            if blk.nreg and blk.training:
+                reg = nat.reg_desc(blk.odefunc.reg_kinds)
+                z, lp, regs, prev = nat.solve_fwd_reg(net, reg, self.flats[i], z, lp, t0, t1, nat.with_after(opts, prev), e,
+                                                      stats=self.stats[i, 0])
+                reg_terms.append((self.reg_coeffs * regs).sum())
+                tape.append((net, t0, t1, opts, e, z, lp, (reg, regs)))
+                continue
             z, lp, prev = nat.solve_fwd(net, self.flats[i], z, lp, t0, t1, nat.with_after(opts, prev), e, stats=self.stats[i, 0],
                                         workspace=self.workspace)
-            tape.append((net, t0, t1, opts, e, z, lp))
+            tape.append((net, t0, t1, opts, e, z, lp, None))
         # the tail: cnf_solve_bwd_train (adjoint + slab sum + Adam in two kernels; for the last block also the loss and its
         # cotangents) where it is built -- hidden width 64, <= 4096 rows -- else cnf_nll_loss, cnf_solve_bwd, cnf_adam_step
         last = len(self.blocks) - 1
         # (fixed-grid solvers: cnf_solve_bwd_train takes the loss kernel's cotangents, at dim <= 2)
         fixed = [tape[i][3].solver != 0 for i in range(last + 1)]
         fused = [self.fuse_tail and tape[i][0].hidden == 64 and z.shape[0] <= 4096 and not (fixed[i] and tape[i][0].dim > 2)
-                 for i in range(last + 1)]
+                 and tape[i][7] is None for i in range(last + 1)]
         loss = gz = gl = None
         if not fused[last] or fixed[last]:
             loss, gz, gl = nat.nll_loss(z, lp)
         for i in range(last, -1, -1):
-            net, t0, t1, opts, e, z1, lp1 = tape[i]
+            net, t0, t1, opts, e, z1, lp1, regd = tape[i]
             opts = nat.with_after(opts, prev)
-            if fused[i]:
+            if regd is not None:
+                gz, gl, gp, prev = nat.solve_bwd_reg(net, regd[0], self.flats[i], z1, lp1, regd[1], gz, gl, self.reg_coeffs, t0, t1, opts, e,
+                                                     stats=self.stats[i, 1])
+                nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], guard=prev, **self.hyper)
+            elif fused[i]:
                 gz, gl, _, l_, prev = nat.solve_bwd_train(net, self.flats[i], z1, lp1, gz, gl, t0, t1, opts, self.exp_avg[i],
                                                           self.exp_avg_sq[i], self.adam_state[i], e, stats=self.stats[i, 1],
                                                           workspace=self.workspace, **self.hyper)
@@ -309,6 +327,8 @@ class FusedTrainStep:
                 nat.adam_step(self.flats[i], gp, self.exp_avg[i], self.exp_avg_sq[i], self.adam_state[i], guard=prev, **self.hyper)
             if self.consts[i] is not None:
                 self.flats[i].index_copy_(0, *self.consts[i])
+        for term in reg_terms:
+            loss = loss + term
         return loss
 
     def __call__(self, x=None):
@@ -538,9 +558,8 @@ def main(argv=None):
     if reg_fns:
         if args.solver != "dopri5" or args.dims != "64-64-64" or args.adjoint_error_control != "state_only":
             raise SystemExit("--l1int / --l2int: built for dopri5, --dims 64-64-64 and the default adjoint error control")
-        if args.fused or args.graphed:
-            logger.info("regularised dynamics train through the eager autograd + torch.optim.Adam loop")
-        args.fused = args.graphed = 0
+        args.graphed = 0   # (the regularisers' states are read by the loss between the solves: FusedTrainStep captures that, the
+        #                     autograd loop runs eagerly)
     if args.fused and (args.layer_type in ("concat", "concatcoord") or args.batch_norm):
         logger.info("autograd + torch.optim.Adam loop (FusedTrainStep updates chains of CNF blocks whose parameters have places "
                     "of their own in the kernels' layout: not 'concat' layers, no batch norm between blocks)")
@@ -560,7 +579,7 @@ def main(argv=None):
     train_sampler = on_device if (args.fused and on_device is not None) else None
     if args.fused:
         x = data.get_sample(args.batch_size).to(device)
-        fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay, sampler=train_sampler)
+        fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay, sampler=train_sampler, reg_coeffs=reg_coeffs or None)
     else:
         graphed_ok = bool(args.graphed) and not args.batch_norm and not args.resume
         optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
@@ -584,7 +603,8 @@ def main(argv=None):
             on_device = data.device_sampler(device)
             train_sampler = on_device if args.fused else None
         if fused is not None:
-            fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay, sampler=train_sampler)   # parameters were re-assigned: re-alias
+            fused = FusedTrainStep(model, x, lr=args.lr, weight_decay=args.weight_decay, sampler=train_sampler,
+                                   reg_coeffs=reg_coeffs or None)   # parameters were re-assigned: re-alias
             fused.load_state_dict(ck["optimizer"])
         else:
             optimizer.load_state_dict(ck["optimizer"])

@@ -165,6 +165,47 @@ def test_fused_train_step_other_layer_types_and_padded_widths(layer_type, dims, 
     assert rel_err(z1, z2) < 1e-4 and rel_err(dl1, dl2) < 1e-3
 
 
+@pytest.mark.parametrize("graph,blocks,kinds", [(True, 1, ("l1", "l2")), (False, 2, ("l2",))])
+def test_fused_train_step_with_kinetic_regularisers_matches_autograd_loop(graph, blocks, kinds):
+    """`--l1int` / `--l2int` through FusedTrainStep: cnf_solve_fwd_reg, the loss nll + sum c_k r_k, cnf_solve_bwd_reg with the
+    constant cotangents c_k, cnf_adam_step -- library kernels only, captured or eager -- against the autograd +
+    torch.optim.Adam loop over the same solves (compute_loss + get_regularization)."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gu import make_gu
+    from gan_flow_amd.lib.layers.wrappers import cnf_regularization as creg
+    fns = tuple({"l1": creg.l1_regularzation_fn, "l2": creg.l2_regularzation_fn}[k] for k in kinds)
+    coeffs = [0.5, 0.25][:len(kinds)]
+    data = make_gu(8, seed=3)
+    batches = [data.get_sample(1024).to(DEV) for _ in range(6)]
+
+    def build():
+        torch.manual_seed(5)
+        return gu_ffjord.build_model(2, num_blocks=blocks, regularization_fns=fns).to(DEV).train()
+
+    ref = build()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-5)
+    ref_losses = []
+    for x in batches:
+        opt.zero_grad(set_to_none=True)
+        loss = gu_ffjord.compute_loss(ref, x)
+        loss = loss + gu_ffjord.get_regularization(ref, coeffs)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    model = build()
+    with pytest.raises(ValueError, match="reg_coeffs"):
+        gu_ffjord.FusedTrainStep(model, batches[0], graph=False)
+    step = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=graph, reg_coeffs=coeffs)
+    losses = [step(x).item() for x in batches]
+    nfe = step.check()
+    print("reference", ["%.5f" % v for v in ref_losses])
+    print("fused    ", ["%.5f" % v for v in losses], nfe)
+    assert all(abs(a - b) <= 2e-5 * abs(a) for a, b in zip(ref_losses, losses))
+    pr = torch.cat([p.detach().reshape(-1) for p in ref.parameters() if p.requires_grad])
+    pf = torch.cat([p.detach().reshape(-1) for p in model.parameters() if p.requires_grad])
+    assert (pr - pf).abs().max().item() < 5e-5
+
+
 @pytest.mark.parametrize("solver,step_size,graph,blocks", [("rk4", 0.05, True, 1), ("rk4", 0.125, False, 2), ("midpoint", 0.05, True, 1),
                                                            ("euler", None, False, 1)])
 def test_fused_train_step_fixed_grid_matches_autograd_loop(solver, step_size, graph, blocks):
