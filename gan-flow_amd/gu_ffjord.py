@@ -514,7 +514,7 @@ def parse_args(argv=None):
                    help="which tensors of the adjoint state steer the backward solve: (z, logp) as the reference's length-2 "
                         "tolerance lists do (default), or the per-row adjoints as well (CNF_FLAG_ADJ_CONTROL_ALL; not in the reference)")
     p.add_argument("--l1int", type=float, default=None, help="coefficient of the l1 kinetic regulariser (ffjord/train_misc.py's "
-                   "flag: integral of the batch mean of mean_i |dz_i/dt|); trains through the autograd loop")
+                   "flag: integral of the batch mean of mean_i |dz_i/dt|)")
     p.add_argument("--l2int", type=float, default=None, help="coefficient of the l2 kinetic regulariser (||dz/dt|| / sqrt(d))")
     p.add_argument("--eval_size", type=int, default=100000)
     p.add_argument("--seed", type=int, default=1)
