@@ -1273,7 +1273,13 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     float* slab = dbg_ws(a, a.slab + (size_t)blockIdx.x * make_layout(D, kH).total, sizeof(float) * make_layout(D, kH).total, __LINE__);
 
     GridSync gs{dbg_gran(a, __LINE__), (int)gridDim.x, 0u};
-    const double nl = (double)a.rows, nz = nl * D;
+    // kRematCtlNote: the batch sizes as doubles and the end time are formed where they are used (once per attempt) from an
+    // opaque copy of the kernel argument -- hoisted, each is a 64-bit value that lives through the whole solve in registers
+    // the evaluation needs (spilled to scratch at 256 registers per wave)
+    auto rows_d = [&]() __attribute__((always_inline)) { long r = a.rows; asm volatile("" : "+s"(r)); return (double)r; };
+    auto rows_d_long = [&]() __attribute__((always_inline)) { long r = a.rows; asm volatile("" : "+s"(r)); return r; };
+    auto nl_ = [&]() __attribute__((always_inline)) { return rows_d(); };
+    auto nz_ = [&]() __attribute__((always_inline)) { return rows_d() * D; };
 
     // a.loss_out: the cotangents are those of loss = -mean(sum_d log N(z1_d) - logp1) (nll_loss_kernel's arithmetic,
     // cnf_train.hip); the loss itself rides on the second grid reduction, whose third slot is free
@@ -1309,7 +1315,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     for (int c = 0; c < C; ++c) yi[c] = y0[c];
 
     const float sgn = a.t0 >= a.t1 ? 1.f : -1.f;
-    const double tau_end = (double)(sgn * a.t0);
+    auto tau_end_ = [&]() __attribute__((always_inline)) { float t0 = a.t0; asm volatile("" : "+s"(t0)); return (double)(sgn * t0); };
     double tau = (double)(sgn * a.t1);
     double dt = 0.0;
     float dtf = 0.f, t0f = (float)tau, ti = t0f;
@@ -1456,17 +1462,17 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                 }
                 if (!wg_allreduce4<false, P>(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
-            const float d0z = (float)sqrt(S[0] / nz), d0l = (float)sqrt(S[1] / nl);
-            d1z = (float)sqrt(S[2] / nz);
-            d1l = (float)sqrt(S[3] / nl);
+            const float d0z = (float)sqrt(S[0] / nz_()), d0l = (float)sqrt(S[1] / nl_());
+            d1z = (float)sqrt(S[2] / nz_());
+            d1l = (float)sqrt(S[3] / nl_());
             float d0a = 0.f, d1a = 0.f, d0al = 0.f;
             if (a.adj_all) {   // CNF_FLAG_ADJ_CONTROL_ALL (cnf_device.h): a_z and a_logp take part in the heuristic
                 double S2[4] = {0, 0, 0, 0};
                 if constexpr (P) adj_all_f0_sums<D, C>(y0, k, al, rtol, atol, counted, S2);
                 if (!wg_allreduce4<false, P>(gs, red, S2, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
-                d0a = (float)sqrt(S2[0] / nz);
-                d1a = (float)sqrt(S2[1] / nz);
-                d0al = (float)sqrt(S2[2] / nl);
+                d0a = (float)sqrt(S2[0] / nz_());
+                d1a = (float)sqrt(S2[1] / nz_());
+                d0al = (float)sqrt(S2[2] / nl_());
                 if (tid == 0) red.keep[0] = d1a;   // read after the next reduction's barriers
             }
             h0 = initial_h0(d0z, d0l, d1z, d1l, a.adj_all != 0, d0a, d1a, d0al);
@@ -1501,9 +1507,9 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                 }
                 if (!wg_allreduce4<false, P>(gs, red, S, w, lane_r)) { status = CNF_ERR_SYNC_TIMEOUT; break; }
             }
-            if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * inv_rows);
-            const float d2z = (float)sqrt(S[0] / nz) / h0, d2l = (float)sqrt(S[1] / nl) / h0;
-            const float d2a = (float)sqrt(S[3] / nz) / h0;
+            if (nll && blockIdx.x == 0 && tid == 0) *a.loss_out = -((float)S[2] * (1.0f / (float)rows_d_long()));   // inv_rows, formed here (kRematCtlNote)
+            const float d2z = (float)sqrt(S[0] / nz_()) / h0, d2l = (float)sqrt(S[1] / nl_()) / h0;
+            const float d2a = (float)sqrt(S[3] / nz_()) / h0;
             dt = (double)initial_dt(h0, d1z, d1l, d2z, d2l, a.adj_all != 0, a.adj_all ? red.keep[0] : 0.f, d2a);
             restart = true;
         } else {
@@ -1544,8 +1550,8 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                 }
                 pr.mark(22);
                 if (S[2] > 0.0) { status = CNF_ERR_NONFINITE; break; }
-                const float rz = (float)(S[0] / nz), rl = (float)(S[1] / nl);
-                const float ra = (float)(S[3] / nz);   // 0 unless CNF_FLAG_ADJ_CONTROL_ALL (a_logp's ratio is always 0)
+                const float rz = (float)(S[0] / nz_()), rl = (float)(S[1] / nl_());
+                const float ra = (float)(S[3] / nz_());   // 0 unless CNF_FLAG_ADJ_CONTROL_ALL (a_logp's ratio is always 0)
                 const bool accept = (rz <= 1.f) && (rl <= 1.f) && (ra <= 1.f);
                 if (accept) {
                     ++nacc;
@@ -1556,7 +1562,7 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                     } else if constexpr (RUNTOT) commit_total<D>(sb, total, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], tid, part);
                     else if constexpr (FSAL) commit_step_fsal<D>(sb, acc, gfirst, glast, i_first, i_last, wq[0], wq[6], slab, tid, nacc == 1, part);
                     else commit_step_split<D>(sb, acc, slab, tid, nacc == 1, part);
-                    if (!(tau_end > tau + dt)) break;
+                    if (!(tau_end_() > tau + dt)) break;
                     if constexpr (P) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) y0[c] = y1[c];
@@ -1605,11 +1611,11 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                 constexpr float kM[7] = {(float)(6025192743.0 / 30085553152.0 / 2), 0.f, (float)(51252292925.0 / 65400821598.0 / 2),
                                          (float)(-2691868925.0 / 45128329728.0 / 2), (float)(187940372067.0 / 1594534317056.0 / 2),
                                          (float)(-1776094331.0 / 19743644256.0 / 2), (float)(11237099.0 / 235043384.0 / 2)};
-                if (tau_end > tau + dt) {
+                if (tau_end_() > tau + dt) {
 #pragma unroll
                     for (int s_ = 0; s_ < 7; ++s_) wq[s_] = s_ < 6 ? dtf * kB[s_] : 0.f;
                 } else {
-                    const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+                    const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end_();
                     const float x = (te - ta) / (tb - ta);
                     const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
 #pragma unroll
@@ -1620,6 +1626,11 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
                         if (s_ == 6) v += dtf * (2.f * x4 - 3.f * x3 + x2);
                         wq[s_] = v;
                     }
+                }
+                // every lane has computed the same seven weights: keep them as wave-uniform (scalar) values
+                if constexpr (TW) {
+#pragma unroll
+                    for (int s_ = 0; s_ < 7; ++s_) wq[s_] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wq[s_])));
                 }
             }
             if constexpr (!TW) __syncthreads();
@@ -1640,8 +1651,13 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
     }
 
     const unsigned taken = grid_ticket(gs, tid);   // all waves are past the last reduction's closing barrier
+    int lane_x = lane;   // the row index of the outputs, formed here (kRematCtlNote)
+    asm volatile("" : "+v"(lane_x));
+    unsigned bx = blockIdx.x;
+    asm volatile("" : "+s"(bx));
+    const long row_e = (long)(a.spread ? (int)(bx >> 1) : (int)bx) * kRows + (lane_x & 15);
     if (P && status == 0) {
-        const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end;
+        const float ta = (float)tau, tb = (float)(tau + dt), te = (float)tau_end_();
         const float x = (te - ta) / (tb - ta);
         const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
 #pragma unroll
@@ -1657,9 +1673,9 @@ __global__ __launch_bounds__(TW ? 2 * kThreads : kThreads) void dopri5_bwd_split
             const float cc = (-4 * dtf) * f0 + dtf * f1 + -11 * u + -5 * v + 16 * mid;
             const float cd = dtf * f0;
             const float out = ca * x4 + cb * x3 + cc * x2 + cd * x + u;
-            if (counted) a.grad_x[row * D + m] = out;
+            if (counted) a.grad_x[row_e * D + m] = out;
         }
-        if (counted) a.grad_logp0[row] = al;
+        if (counted) a.grad_logp0[row_e] = al;
     }
     if constexpr (TW) {
         if constexpr (T) {
