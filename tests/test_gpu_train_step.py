@@ -379,6 +379,47 @@ def test_fused_train_step_d16_hutchinson_gmm(graph):
         assert e1 is not e2 and not torch.equal(e1, e2)       # a new probe per iteration
 
 
+@pytest.mark.parametrize("solver,step_size", [("rk4", 0.1), ("midpoint", 0.05)])
+def test_fused_train_step_d16_fixed_grid_matches_autograd_loop(solver, step_size):
+    """d = 16 with a fixed-grid solver through FusedTrainStep (gmm_ffjord --solver rk4): the unfused tail -- cnf_nll_loss,
+    cnf_solve_bwd on fixed_bwd_split16_kernel, cnf_adam_step -- in one captured iteration, against the autograd +
+    torch.optim.Adam loop over the same solves with the same Rademacher probes."""
+    from gan_flow_amd import gu_ffjord
+    from gan_flow_amd.gmm import GaussianMixture
+    data = GaussianMixture(16, device=DEV, sample_seed=3)
+    batches = [data.get_sample(2048) for _ in range(5)]
+
+    def build():
+        torch.manual_seed(3)
+        m = gu_ffjord.build_model(16, divergence_fn="approximate", solver=solver, rademacher=True).to(DEV).train()
+        for blk in m.chain:
+            blk.solver_options = {"step_size": step_size}
+        return m
+
+    ref = build()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-5)
+    torch.manual_seed(77)
+    ref_losses = []
+    for x in batches:
+        opt.zero_grad(set_to_none=True)
+        loss = gu_ffjord.compute_loss(ref, x)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    model = build()
+    step = gu_ffjord.FusedTrainStep(model, batches[0], lr=1e-3, weight_decay=1e-5, graph=False)
+    torch.manual_seed(77)
+    losses = [step(x).item() for x in batches]
+    nfe = step.check()
+    print("reference", ["%.5f" % v for v in ref_losses])
+    print("fused    ", ["%.5f" % v for v in losses], nfe)
+    assert nfe[0] == nfe[1] == {"rk4": 4, "midpoint": 2}[solver] * round(0.5 / step_size)
+    assert all(abs(a - b) <= 2e-5 * abs(a) for a, b in zip(ref_losses, losses))
+    pr = torch.cat([p.detach().reshape(-1) for p in ref.parameters() if p.requires_grad])
+    pf = torch.cat([p.detach().reshape(-1) for p in model.parameters() if p.requires_grad])
+    assert (pr - pf).abs().max().item() < 5e-5
+
+
 def test_concurrent_trials_match_sequential():
     """Two trainings replayed on two streams of one GPU (gu_ffjord.ConcurrentTrials) follow exactly the trajectories they
     follow alone: the kernels are deterministic and share nothing but the device."""
